@@ -1,0 +1,84 @@
+"""ctypes loader for libpbnet_hip.so (the C ABI declared in include/pbnet_hip.h).
+
+The library is the product: there is NO CPU fallback.  If it is missing or fails to load this module raises,
+loudly, instead of routing anywhere else.  torch is used only to own device memory and streams.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpbnet_hip.so")
+
+_lib = None
+
+c_f32p = ctypes.c_void_p
+c_i32p = ctypes.c_void_p
+c_vp = ctypes.c_void_p
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/pbnet_hip.h (tests/test_abi.py checks this)
+SIGNATURES = {
+    "pbn_version": (ctypes.c_char_p, []),
+    "pbn_last_hip_error": (c_int, []),
+    "pbn_cluster_workspace_bytes": (c_size, [c_int, c_int, c_int]),
+    "pbn_binary_cluster": (c_int, [c_f32p, c_f32p, c_i32p, c_i32p, c_int, c_int, c_float, c_int, c_float, c_int, c_int,
+                                   c_i32p, c_i32p, c_i32p, c_f32p, c_i32p, c_i32p, c_i32p, c_i32p, c_vp, c_size, c_vp]),
+    "pbn_get_iou": (c_int, [c_i32p, c_i32p, c_vp, c_i32p, c_f32p, c_int, c_int, c_vp]),
+    "pbn_cal_iou_and_masklabel": (c_int, [c_i32p, c_i32p, c_vp, c_i32p, c_f32p, c_int, c_int, c_f32p, c_f32p, c_int,
+                                          c_vp]),
+}
+
+ERRORS = {-1: "PBN_ERR_ARG", -2: "PBN_ERR_WORKSPACE", -3: "PBN_ERR_HIP", -4: "PBN_ERR_RANGE", -5: "PBN_ERR_UNSUPPORTED"}
+
+
+class NativeLibraryError(ImportError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises NativeLibraryError when the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                "libpbnet_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C pbnet_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # missing ROCm runtime etc.
+            raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        detail = ""
+        if rc == -3:
+            detail = " (hipError %d)" % lib().pbn_last_hip_error()
+        raise RuntimeError("%s failed: %s%s" % (what, ERRORS.get(rc, str(rc)), detail))
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pbnet_amd runs on the MI355X only: got a %s tensor (no CPU path)" % t.device)

@@ -1,0 +1,584 @@
+// cluster.hip -- point-wise binarization + neighbour clustering on gfx950 (wave64).
+//
+// Replaces the Solver pipeline of /root/reference/lib/PB_lib/src/pbnet/{cluster.cu,binary.cu,binary_cuda_functions.cu}
+// with a batch-of-segments pipeline that never leaves the device and never materialises the adjacency:
+//
+//   seg offsets -> uniform grid hash (cell = 1.0625 r) -> cell-sorted point slab -> exact r-ball count (+HP flag)
+//   -> lock-free union-find over HP-HP pairs (min-index roots) -> border LP = max adjacent seed
+//   -> sizes -> keep flags -> scan = final ids -> exact NN for unassigned points -> ordered members + centres
+//
+// Determinism: every output is a function of the input only (atomics are used on integers where the result is
+// order independent: min, max, add).  Floating point follows oracle/pb_cluster_ref.c exactly: unfused binary32
+// d2 = (dx*dx+dy*dy)+dz*dz, d2 <= r*r, sequential running mean with IEEE division.  This file MUST be compiled
+// with -ffp-contract=off (see csrc/Makefile); the pragma below is a second line of defence.
+#include "pbn_common.h"
+
+#pragma clang fp contract(off)
+
+namespace pbn {
+namespace {
+
+constexpr int TPB = 256;
+constexpr unsigned long long EMPTY_KEY = ~0ULL;
+constexpr int CELL_BIAS = 32768;
+constexpr float CELL_CLAMP = 32766.0f;
+constexpr int BIG = 0x7f7f7f7f;  // memset(0x7f) pattern: "no seed yet"
+
+// lib/PB_lib/src/pbnet/binary.cu:229 ("mean count from HAIS"), indexed by sem-2
+__constant__ float c_mean_count[18] = {3917.0f, 12056.0f, 2303.0f, 8331.0f, 3948.0f, 3166.0f, 5629.0f, 11719.0f, 1003.0f,
+                                       3317.0f, 4912.0f,  10221.0f, 3889.0f, 4136.0f, 2120.0f, 945.0f,  3967.0f, 2589.0f};
+
+// binary_cuda_functions.cu:305-308 in the fixed unfused form
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+    const float a = __fmul_rn(dx, dx), b = __fmul_rn(dy, dy), c = __fmul_rn(dz, dz);
+    return __fadd_rn(__fadd_rn(a, b), c);
+}
+
+__device__ __forceinline__ int cls_of(int sem) { return min(max(sem - 2, 0), 17); }  // index into 18-entry tables
+
+__device__ __forceinline__ int cell_coord(float v, float inv_cell) {
+    float f = floorf(v * inv_cell);
+    f = fminf(fmaxf(f, -CELL_CLAMP), CELL_CLAMP);  // also maps NaN to -CELL_CLAMP
+    return (int)f;
+}
+
+__device__ __forceinline__ unsigned long long pack_key(int seg, int cx, int cy, int cz) {
+    return ((unsigned long long)(unsigned)seg << 48) | ((unsigned long long)(unsigned)(cx + CELL_BIAS) << 32) |
+           ((unsigned long long)(unsigned)(cy + CELL_BIAS) << 16) | (unsigned long long)(unsigned)(cz + CELL_BIAS);
+}
+
+__device__ __forceinline__ int hash_lookup(const unsigned long long* __restrict__ hkeys, unsigned hmask,
+                                           unsigned long long key) {
+    unsigned h = hash64(key) & hmask;
+    while (true) {
+        unsigned long long k = hkeys[h];
+        if (k == key) return (int)h;
+        if (k == EMPTY_KEY) return -1;
+        h = (h + 1) & hmask;
+    }
+}
+
+// ---- segment offsets: exclusive scan of seg_len by one wave; status != 0 when the lengths do not add up -------
+__global__ void k_seg_offsets(const int* __restrict__ seg_len, int n_seg, int n, int* __restrict__ seg_off,
+                              int* __restrict__ status) {
+    const int lane = lane_id();
+    int carry = 0;
+    int bad = 0;
+    for (int base = 0; base < n_seg; base += 64) {
+        int i = base + lane;
+        int v = (i < n_seg) ? seg_len[i] : 0;
+        if (v < 0) bad = 1;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (i < n_seg) seg_off[i] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    bad = __any(bad);
+    if (lane == 0) {
+        seg_off[n_seg] = carry;
+        if (carry != n || bad) atomicOr(status, 1);
+    }
+}
+
+__device__ __forceinline__ int find_segment(const int* __restrict__ seg_off, int n_seg, int i) {
+    int lo = 0, hi = n_seg;  // largest s with seg_off[s] <= i
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (seg_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- grid hash build: one slot per occupied (segment, cell); per-slot population ------------------------------
+__global__ __launch_bounds__(TPB) void k_cell_insert(const float* __restrict__ off_xyz, const int* __restrict__ sem,
+                                                    const int* __restrict__ seg_off, int n_seg, int n, float inv_cell,
+                                                    unsigned long long* __restrict__ hkeys, int* __restrict__ hcount,
+                                                    unsigned hmask, int* __restrict__ slot_of_pt,
+                                                    int* __restrict__ seg_of_pt, int* __restrict__ status) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int s = sem[i];
+    if (s < 2 || s > 19) atomicOr(status, 2);
+    const int seg = find_segment(seg_off, n_seg, i);
+    seg_of_pt[i] = seg;
+    const float x = off_xyz[3 * i + 0], y = off_xyz[3 * i + 1], z = off_xyz[3 * i + 2];
+    const unsigned long long key = pack_key(seg, cell_coord(x, inv_cell), cell_coord(y, inv_cell), cell_coord(z, inv_cell));
+    unsigned h = hash64(key) & hmask;
+    while (true) {
+        unsigned long long prev = atomicCAS(&hkeys[h], EMPTY_KEY, key);
+        if (prev == EMPTY_KEY || prev == key) break;
+        h = (h + 1) & hmask;
+    }
+    atomicAdd(&hcount[h], 1);
+    slot_of_pt[i] = (int)h;
+}
+
+// ---- scatter points into the cell-sorted slab: float4(x, y, z, bits(original index)) --------------------------
+__global__ __launch_bounds__(TPB) void k_cell_scatter(const float* __restrict__ off_xyz, int n,
+                                                     const int* __restrict__ slot_of_pt, const int* __restrict__ hstart,
+                                                     int* __restrict__ hcursor, const int* __restrict__ seg_of_pt,
+                                                     float4* __restrict__ spt, int* __restrict__ sseg) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int slot = slot_of_pt[i];
+    const int pos = hstart[slot] + atomicAdd(&hcursor[slot], 1);
+    spt[pos] = make_float4(off_xyz[3 * i + 0], off_xyz[3 * i + 1], off_xyz[3 * i + 2], __int_as_float(i));
+    sseg[pos] = seg_of_pt[i];
+}
+
+// Enumerate the 27 cells around point (x,y,z) of segment seg; F(beg, end) is called per occupied cell.
+template <typename F>
+__device__ __forceinline__ void for_each_neighbour_cell(float x, float y, float z, int seg, float inv_cell,
+                                                        const unsigned long long* __restrict__ hkeys, unsigned hmask,
+                                                        const int* __restrict__ hstart, const int* __restrict__ hcount,
+                                                        F&& f) {
+    const int cx = cell_coord(x, inv_cell), cy = cell_coord(y, inv_cell), cz = cell_coord(z, inv_cell);
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int slot = hash_lookup(hkeys, hmask, pack_key(seg, cx + dx, cy + dy, cz + dz));
+                if (slot < 0) continue;
+                const int beg = hstart[slot];
+                f(beg, beg + hcount[slot]);
+            }
+}
+
+// ---- a10/a12: exact r-ball population (self excluded) ; thread per cell-sorted position --------------------------
+__global__ __launch_bounds__(TPB) void k_count(const float4* __restrict__ spt, const int* __restrict__ sseg, int n,
+                                              float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
+                                              unsigned hmask, const int* __restrict__ hstart,
+                                              const int* __restrict__ hcount, int* __restrict__ den) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= n) return;
+    const float4 me = spt[p];
+    int cnt = 0;
+    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount, [&](int beg, int end) {
+        for (int j = beg; j < end; ++j) {
+            const float4 q = spt[j];
+            cnt += (sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) ? 1 : 0;
+        }
+    });
+    den[__float_as_int(me.w)] = cnt - 1;  // binary_cuda_functions.cu:88
+}
+
+// tag the HP flag into bit 31 of the index word of the sorted slab; init union-find parents
+__global__ __launch_bounds__(TPB) void k_tag_hp(float4* __restrict__ spt, int n, const int* __restrict__ den, int min_pts,
+                                               int* __restrict__ parent, int* __restrict__ lab) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= n) return;
+    const int i = __float_as_int(spt[p].w);
+    const int hp = den[i] >= min_pts;  // binary_cuda_functions.cu:185
+    spt[p].w = __int_as_float(i | (hp ? (int)0x80000000 : 0));
+    parent[i] = i;
+    lab[i] = -1;
+}
+
+// ---- lock-free union-find; roots are always the smallest index of their set -----------------------------------
+__device__ __forceinline__ int uf_load(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int uf_find(int* __restrict__ parent, int x) {
+    while (true) {
+        const int p = uf_load(&parent[x]);
+        if (p == x) return x;
+        const int gp = uf_load(&parent[p]);
+        if (gp == p) return p;
+        atomicMin(&parent[x], gp);  // path halving; monotone, so concurrent hooks are never lost
+        x = gp;
+    }
+}
+
+__device__ __forceinline__ int uf_union(int* __restrict__ parent, int a, int b) {
+    while (true) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return a;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&parent[a], b);  // hook the larger root under the smaller
+        if (old == a) return b;
+        a = old;  // a had been hooked meanwhile: keep merging its new parent with b
+    }
+}
+
+// a13: connected components of the HP graph; each undirected edge is handled by its larger endpoint
+__global__ __launch_bounds__(TPB) void k_union(const float4* __restrict__ spt, const int* __restrict__ sseg, int n,
+                                              float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
+                                              unsigned hmask, const int* __restrict__ hstart,
+                                              const int* __restrict__ hcount, int* __restrict__ parent) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= n) return;
+    const float4 me = spt[p];
+    const int wi = __float_as_int(me.w);
+    if (wi >= 0) return;  // LP: never expands (binary_cuda_functions.cu:209)
+    const int i = wi & 0x7fffffff;
+    int ri = uf_find(parent, i);
+    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount, [&](int beg, int end) {
+        for (int j = beg; j < end; ++j) {
+            const float4 q = spt[j];
+            const int wj = __float_as_int(q.w);
+            const int jj = wj & 0x7fffffff;
+            if (wj < 0 && jj < i && sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) {
+                if (uf_load(&parent[jj]) != ri) ri = uf_union(parent, ri, jj);
+            }
+        }
+    });
+}
+
+// HP: lab = root (general mode: also register the smallest same-class HP of the component)
+__global__ __launch_bounds__(TPB) void k_flatten(const float4* __restrict__ spt, int n, int* __restrict__ parent,
+                                                const int* __restrict__ sem, int general, int* __restrict__ semseed,
+                                                int* __restrict__ lab) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= n) return;
+    const int wi = __float_as_int(spt[p].w);
+    if (wi >= 0) return;
+    const int i = wi & 0x7fffffff;
+    const int r = uf_find(parent, i);
+    lab[i] = r;
+    if (general) atomicMin(&semseed[(size_t)cls_of(sem[i]) * n + r], i);
+}
+
+// general mode: HP label = seed of (component, class)
+__global__ __launch_bounds__(TPB) void k_hp_seed_general(const float4* __restrict__ spt, int n, const int* __restrict__ sem,
+                                                        const int* __restrict__ semseed, int* __restrict__ lab) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= n) return;
+    const int wi = __float_as_int(spt[p].w);
+    if (wi >= 0) return;
+    const int i = wi & 0x7fffffff;
+    lab[i] = semseed[(size_t)cls_of(sem[i]) * n + lab[i]];
+}
+
+// a13 (border rule): an LP within r of HPs takes the LAST cluster that reached it = the largest seed index among
+// clusters (component of an adjacent HP, class of the LP) -- binary.cu:206-209.  `root` holds component roots of HPs.
+__global__ __launch_bounds__(TPB) void k_border(const float4* __restrict__ spt, const int* __restrict__ sseg, int n,
+                                               float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
+                                               unsigned hmask, const int* __restrict__ hstart,
+                                               const int* __restrict__ hcount, const int* __restrict__ sem, int general,
+                                               const int* __restrict__ semseed, const int* __restrict__ root,
+                                               int* __restrict__ lab) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= n) return;
+    const float4 me = spt[p];
+    const int wi = __float_as_int(me.w);
+    if (wi < 0) return;  // HP
+    const int i = wi;
+    const int my_sem = sem[i];
+    int best = -1;
+    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount, [&](int beg, int end) {
+        for (int j = beg; j < end; ++j) {
+            const float4 q = spt[j];
+            const int wj = __float_as_int(q.w);
+            if (wj < 0 && sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) {
+                const int jj = wj & 0x7fffffff;
+                int s;
+                if (general) {
+                    s = semseed[(size_t)cls_of(my_sem) * n + root[jj]];
+                    if (s == BIG) s = -1;
+                } else {
+                    s = root[jj];
+                }
+                best = max(best, s);
+            }
+        }
+    });
+    lab[i] = best;
+}
+
+__global__ __launch_bounds__(TPB) void k_copy_i32(const int* __restrict__ src, int* __restrict__ dst, int n) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// a14: cluster population (HPs + border LPs) per seed
+__global__ __launch_bounds__(TPB) void k_sizes(const int* __restrict__ lab, int n, int* __restrict__ size) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int s = lab[i];
+    if (s >= 0) atomicAdd(&size[s], 1);
+}
+
+// a14: keep flag per seed: dropped iff float(size) < mean_count[sem-2] * para_f (binary.cu:255-256)
+__global__ __launch_bounds__(TPB) void k_keep(const int* __restrict__ lab, const int* __restrict__ size,
+                                             const int* __restrict__ sem, int n, float para_f, int* __restrict__ keep) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    int k = 0;
+    if (lab[i] == i) {
+        const int cs = cls_of(sem[i]);
+        const float thr = __fmul_rn(c_mean_count[cs], para_f);
+        k = ((float)size[i] < thr) ? 0 : 1;
+    }
+    keep[i] = k;
+}
+
+// final ids after filtering; candidates for the NN search; per-cluster bookkeeping
+__global__ __launch_bounds__(TPB) void k_relabel(const int* __restrict__ lab, const int* __restrict__ keep,
+                                                const int* __restrict__ newid, const int* __restrict__ sem,
+                                                const int* __restrict__ seg_of_pt, const float* __restrict__ org_xyz,
+                                                int n, int* __restrict__ lab2, int* __restrict__ cluster_id,
+                                                int* __restrict__ clt_sem, int* __restrict__ clt_seg,
+                                                int* __restrict__ last_assigned, int* __restrict__ fsize,
+                                                int* __restrict__ noise_flag, float4* __restrict__ cand) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int s = lab[i];
+    const int id = (s >= 0 && keep[s]) ? newid[s] : -1;
+    lab2[i] = id;
+    cluster_id[i] = id;
+    noise_flag[i] = id < 0;
+    if (keep[i]) {
+        clt_sem[newid[i]] = sem[i];
+        clt_seg[newid[i]] = seg_of_pt[i];
+    }
+    if (id >= 0) {
+        atomicMax(&last_assigned[seg_of_pt[i]], i);
+        atomicAdd(&fsize[id], 1);
+    }
+    cand[i] = make_float4(org_xyz[3 * i + 0], org_xyz[3 * i + 1], org_xyz[3 * i + 2],
+                          __int_as_float(id >= 0 ? sem[i] : -1));
+}
+
+__global__ void k_cluster_num(const int* __restrict__ newid, const int* __restrict__ seg_off, int n_seg, int n,
+                              const int* __restrict__ total, int* __restrict__ cluster_num,
+                              const int* __restrict__ status, int* __restrict__ n_clusters) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) *n_clusters = (*status != 0) ? -1 : *total;
+    if (b >= n_seg) return;
+    const int lo = seg_off[b], hi = seg_off[b + 1];
+    const int a = (lo < n) ? newid[lo] : *total;
+    const int e = (hi < n) ? newid[hi] : *total;
+    cluster_num[b] = e - a;
+}
+
+__global__ __launch_bounds__(TPB) void k_compact_noise(const int* __restrict__ noise_flag, const int* __restrict__ pos,
+                                                      int n, int* __restrict__ noise_list) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < n && noise_flag[i]) noise_list[pos[i]] = i;
+}
+
+// a15: exact nearest assigned point of the same class, ORIGINAL coordinates, ties -> highest index
+// (binary_cuda_functions.cu:258-302).  Thread per unassigned point; candidates streamed in ascending index so the
+// `<=` update reproduces the reference scan order.
+__global__ __launch_bounds__(TPB) void k_noise_nn(const int* __restrict__ noise_list, const int* __restrict__ n_noise,
+                                                 const float4* __restrict__ cand, const int* __restrict__ sem,
+                                                 const int* __restrict__ seg_of_pt, const int* __restrict__ seg_off,
+                                                 const int* __restrict__ lab2, const int* __restrict__ last_assigned,
+                                                 int* __restrict__ cluster_id, int* __restrict__ fsize) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= *n_noise) return;
+    const int i = noise_list[t];
+    const int seg = seg_of_pt[i];
+    const int beg = seg_off[seg], end = seg_off[seg + 1];
+    const float4 me = cand[i];
+    const int my_sem = sem[i];
+    float best = __builtin_inff();
+    int bi = -1;
+    for (int j = beg; j < end; ++j) {
+        const float4 q = cand[j];
+        if (__float_as_int(q.w) == my_sem) {
+            const float d = sqdist(me.x, me.y, me.z, q.x, q.y, q.z);
+            if (d <= best) { best = d; bi = j; }
+        }
+    }
+    if (bi < 0) bi = last_assigned[seg];  // no assigned point of this class: binary_cuda_functions.cu:287-299
+    const int id = (bi >= 0) ? lab2[bi] : -1;
+    cluster_id[i] = id;
+    if (id >= 0) atomicAdd(&fsize[id], 1);
+}
+
+// a16 + members CSR: one wave per final cluster walks its segment in index order, compacts its members and feeds
+// the sequential running mean M += (p - M)/N (binary_cuda_functions.cu:237-239); all lanes carry the same M.
+__global__ __launch_bounds__(TPB) void k_centers(const int* __restrict__ cluster_id, const float* __restrict__ off_xyz,
+                                                const int* __restrict__ clt_seg, const int* __restrict__ seg_off,
+                                                const int* __restrict__ n_clusters_total,
+                                                const int* __restrict__ member_start, int* __restrict__ member_idx,
+                                                float* __restrict__ centers) {
+    const int lane = lane_id();
+    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * TPB) >> 6;
+    const int C = *n_clusters_total;
+    for (int c = wave; c < C; c += n_waves) {
+        const int seg = clt_seg[c];
+        const int beg = seg_off[seg], end = seg_off[seg + 1];
+        int wpos = member_start ? member_start[c] : 0;
+        int N = 0;
+        float mx = 0.f, my = 0.f, mz = 0.f;
+        for (int base = beg; base < end; base += 64) {
+            const int i = base + lane;
+            const bool hit = (i < end) && (cluster_id[i] == c);
+            float px = 0.f, py = 0.f, pz = 0.f;
+            if (hit) { px = off_xyz[3 * i + 0]; py = off_xyz[3 * i + 1]; pz = off_xyz[3 * i + 2]; }
+            unsigned long long mask = __ballot(hit);
+            if (member_idx && hit) member_idx[wpos + __popcll(mask & ((1ULL << lane) - 1ULL))] = i;
+            wpos += __popcll(mask);
+            while (mask) {
+                const int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const float x = __shfl(px, b, 64), y = __shfl(py, b, 64), z = __shfl(pz, b, 64);
+                ++N;
+                const float fn = (float)N;
+                mx = __fadd_rn(mx, __fdiv_rn(__fsub_rn(x, mx), fn));
+                my = __fadd_rn(my, __fdiv_rn(__fsub_rn(y, my), fn));
+                mz = __fadd_rn(mz, __fdiv_rn(__fsub_rn(z, mz), fn));
+            }
+        }
+        if (lane == 0) { centers[3 * c + 0] = mx; centers[3 * c + 1] = my; centers[3 * c + 2] = mz; }
+    }
+}
+
+__global__ void k_member_tail(int* __restrict__ member_start, const int* __restrict__ total_assigned, int n,
+                              const int* __restrict__ n_clusters) {
+    // scan wrote member_start[0..n-1]; entries >= C all equal total; write the [n] sentinel
+    if (threadIdx.x == 0 && blockIdx.x == 0) member_start[n] = *total_assigned;
+    (void)n_clusters;
+}
+
+struct Workspace {
+    int *seg_off, *seg_of_pt, *slot_of_pt, *hcount, *hstart, *hcursor, *sseg, *parent, *lab, *root, *semseed, *size,
+        *keep, *newid, *lab2, *clt_seg, *last_assigned, *fsize, *noise_flag, *noise_pos, *noise_list, *scan_tmp,
+        *scalars, *mstart_tmp;
+    unsigned long long* hkeys;
+    float4 *spt, *cand;
+    unsigned hcap;
+};
+
+unsigned hash_capacity(int n) {
+    unsigned c = 1024;
+    while (c < 2u * (unsigned)n) c <<= 1;
+    return c;
+}
+
+size_t carve(Carver& cv, Workspace& w, int n, int n_seg, int general) {
+    const size_t N = (size_t)(n > 0 ? n : 1);
+    w.hcap = hash_capacity(n);
+    w.hkeys = cv.take<unsigned long long>(w.hcap);
+    w.hcount = cv.take<int>(w.hcap);
+    w.hstart = cv.take<int>(w.hcap);
+    w.hcursor = cv.take<int>(w.hcap);
+    w.spt = cv.take<float4>(N);
+    w.cand = cv.take<float4>(N);
+    w.seg_off = cv.take<int>((size_t)n_seg + 1);
+    w.seg_of_pt = cv.take<int>(N);
+    w.slot_of_pt = cv.take<int>(N);
+    w.sseg = cv.take<int>(N);
+    w.parent = cv.take<int>(N);
+    w.lab = cv.take<int>(N);
+    w.root = cv.take<int>(N);
+    w.semseed = cv.take<int>(general ? 18 * N : 1);
+    w.size = cv.take<int>(N);
+    w.keep = cv.take<int>(N);
+    w.newid = cv.take<int>(N);
+    w.lab2 = cv.take<int>(N);
+    w.clt_seg = cv.take<int>(N);
+    w.last_assigned = cv.take<int>((size_t)n_seg + 1);
+    w.fsize = cv.take<int>(N);
+    w.noise_flag = cv.take<int>(N);
+    w.noise_pos = cv.take<int>(N);
+    w.noise_list = cv.take<int>(N);
+    w.mstart_tmp = cv.take<int>(N + 1);
+    w.scan_tmp = cv.take<int>(scan_tmp_ints((long long)(w.hcap > N ? w.hcap : N)));
+    w.scalars = cv.take<int>(16);
+    return align_up(cv.off, 256);
+}
+
+}  // namespace
+}  // namespace pbn
+
+using namespace pbn;
+
+extern "C" size_t pbn_cluster_workspace_bytes(int n_points, int n_segments, int general_sem) {
+    if (n_points < 0 || n_segments < 0) return 0;
+    Carver cv(nullptr, 0);
+    Workspace w;
+    return carve(cv, w, n_points, n_segments, general_sem);
+}
+
+extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, const int32_t* sem,
+                                  const int32_t* seg_len, int n, int n_seg, float radius, int min_pts, float para_f,
+                                  int nv_flag, int general, int32_t* cluster_id, int32_t* cluster_num, int32_t* den,
+                                  float* centers, int32_t* clt_sem, int32_t* n_clusters, int32_t* member_start,
+                                  int32_t* member_idx, void* workspace, size_t workspace_bytes, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || n_seg < 0 || n_seg > 65535 || !(radius > 0.0f) || !n_clusters || (n_seg > 0 && !cluster_num))
+        return PBN_ERR_ARG;
+    if ((member_start == nullptr) != (member_idx == nullptr)) return PBN_ERR_ARG;
+    if (n > 0 && (!off_xyz || !org_xyz || !sem || !seg_len || !cluster_id || !den || !centers || !clt_sem || !workspace))
+        return PBN_ERR_ARG;
+    if (n_seg > 0) PBN_HIP_CHECK(hipMemsetAsync(cluster_num, 0, sizeof(int) * (size_t)n_seg, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(n_clusters, 0, sizeof(int), stream));
+    if (n == 0 || n_seg == 0) {
+        if (member_start) PBN_HIP_CHECK(hipMemsetAsync(member_start, 0, sizeof(int) * ((size_t)n + 1), stream));
+        return PBN_OK;
+    }
+    Carver cv(workspace, workspace_bytes);
+    Workspace w;
+    carve(cv, w, n, n_seg, general);
+    if (!cv.ok) return PBN_ERR_WORKSPACE;
+
+    const float cell = radius * 1.0625f;  // > r so that every r-neighbour lies in the 27 surrounding cells
+    const float inv_cell = 1.0f / cell;
+    const float r2 = radius * radius;      // binary_cuda_functions.cu:85 (fp32 product)
+    const unsigned hmask = w.hcap - 1;
+    const int nb = cdiv(n, TPB);
+    int* status = w.scalars + 0;
+    int* total_kept = w.scalars + 1;
+    int* n_noise = w.scalars + 2;
+    int* total_assigned = w.scalars + 3;
+
+    PBN_HIP_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int) * 16, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(w.hkeys, 0xff, sizeof(unsigned long long) * w.hcap, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(w.hcount, 0, sizeof(int) * w.hcap, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(w.hcursor, 0, sizeof(int) * w.hcap, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(w.size, 0, sizeof(int) * (size_t)n, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(w.fsize, 0, sizeof(int) * (size_t)n, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(w.last_assigned, 0xff, sizeof(int) * ((size_t)n_seg + 1), stream));
+    if (general) PBN_HIP_CHECK(hipMemsetAsync(w.semseed, 0x7f, sizeof(int) * 18 * (size_t)n, stream));
+
+    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(64), 0, stream, seg_len, n_seg, n, w.seg_off, status);
+    hipLaunchKernelGGL(k_cell_insert, dim3(nb), dim3(TPB), 0, stream, off_xyz, sem, w.seg_off, n_seg, n, inv_cell,
+                       w.hkeys, w.hcount, hmask, w.slot_of_pt, w.seg_of_pt, status);
+    int rc = scan_exclusive_i32(w.hcount, w.hstart, (int)w.hcap, w.scan_tmp, nullptr, stream);
+    if (rc != PBN_OK) return rc;
+    hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(TPB), 0, stream, off_xyz, n, w.slot_of_pt, w.hstart, w.hcursor,
+                       w.seg_of_pt, w.spt, w.sseg);
+    hipLaunchKernelGGL(k_count, dim3(nb), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+                       w.hstart, w.hcount, den);
+    hipLaunchKernelGGL(k_tag_hp, dim3(nb), dim3(TPB), 0, stream, w.spt, n, den, min_pts, w.parent, w.lab);
+    hipLaunchKernelGGL(k_union, dim3(nb), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+                       w.hstart, w.hcount, w.parent);
+    hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, stream, w.spt, n, w.parent, sem, general, w.semseed, w.lab);
+    hipLaunchKernelGGL(k_copy_i32, dim3(nb), dim3(TPB), 0, stream, w.lab, w.root, n);
+    if (general)
+        hipLaunchKernelGGL(k_hp_seed_general, dim3(nb), dim3(TPB), 0, stream, w.spt, n, sem, w.semseed, w.lab);
+    hipLaunchKernelGGL(k_border, dim3(nb), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+                       w.hstart, w.hcount, sem, general, w.semseed, w.root, w.lab);
+    hipLaunchKernelGGL(k_sizes, dim3(nb), dim3(TPB), 0, stream, w.lab, n, w.size);
+    hipLaunchKernelGGL(k_keep, dim3(nb), dim3(TPB), 0, stream, w.lab, w.size, sem, n, para_f, w.keep);
+    rc = scan_exclusive_i32(w.keep, w.newid, n, w.scan_tmp, total_kept, stream);
+    if (rc != PBN_OK) return rc;
+    hipLaunchKernelGGL(k_relabel, dim3(nb), dim3(TPB), 0, stream, w.lab, w.keep, w.newid, sem, w.seg_of_pt, org_xyz, n,
+                       w.lab2, cluster_id, clt_sem, w.clt_seg, w.last_assigned, w.fsize, w.noise_flag, w.cand);
+    hipLaunchKernelGGL(k_cluster_num, dim3(cdiv(n_seg, 64)), dim3(64), 0, stream, w.newid, w.seg_off, n_seg, n,
+                       total_kept, cluster_num, status, n_clusters);
+    if (nv_flag) {
+        rc = scan_exclusive_i32(w.noise_flag, w.noise_pos, n, w.scan_tmp, n_noise, stream);
+        if (rc != PBN_OK) return rc;
+        hipLaunchKernelGGL(k_compact_noise, dim3(nb), dim3(TPB), 0, stream, w.noise_flag, w.noise_pos, n, w.noise_list);
+        hipLaunchKernelGGL(k_noise_nn, dim3(nb), dim3(TPB), 0, stream, w.noise_list, n_noise, w.cand, sem, w.seg_of_pt,
+                           w.seg_off, w.lab2, w.last_assigned, cluster_id, w.fsize);
+    }
+    int* mstart = member_start ? member_start : w.mstart_tmp;
+    rc = scan_exclusive_i32(w.fsize, mstart, n, w.scan_tmp, total_assigned, stream);
+    if (rc != PBN_OK) return rc;
+    hipLaunchKernelGGL(k_member_tail, dim3(1), dim3(64), 0, stream, mstart, total_assigned, n, total_kept);
+    const int center_blocks = 1024;  // 4096 waves, persistent over clusters
+    hipLaunchKernelGGL(k_centers, dim3(center_blocks), dim3(TPB), 0, stream, cluster_id, off_xyz, w.clt_seg, w.seg_off,
+                       total_kept, mstart, member_idx, centers);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}

@@ -1,0 +1,115 @@
+// common.hip -- version / error plumbing and the device-wide scan used by the grouping and coordinate kernels.
+#include "pbn_common.h"
+
+namespace pbn {
+
+thread_local int g_last_hip_error = 0;
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of one value per thread (SCAN_THREADS threads); returns exclusive prefix, sets total.
+__device__ __forceinline__ int block_excl_scan(int v, int* lds_wave_tot, int& block_total) {
+    const int lane = lane_id();
+    const int wid = threadIdx.x >> 6;
+    const int nw = SCAN_THREADS / 64;
+    int incl = wave_incl_scan(v);
+    if (lane == 63) lds_wave_tot[wid] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < nw; ++w) {
+        int t = lds_wave_tot[w];
+        if (w < wid) woff += t;
+        tot += t;
+    }
+    block_total = tot;
+    __syncthreads();
+    return woff + incl - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const int* __restrict__ in, int n,
+                                                                  int* __restrict__ sums) {
+    __shared__ int wtot[SCAN_THREADS / 64];
+    const long long base = (long long)blockIdx.x * SCAN_TILE;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        long long i = base + (long long)k * SCAN_THREADS + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+    s = wave_reduce_add(s);
+    if (lane_id() == 0) wtot[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) t += wtot[w];
+        sums[blockIdx.x] = t;
+    }
+}
+
+// Single block: exclusive scan of nb block sums in place; total -> sums[nb] and *total.
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(int* __restrict__ sums, int nb, int* __restrict__ total) {
+    __shared__ int wtot[SCAN_THREADS / 64];
+    int carry = 0;
+    for (int base = 0; base < nb; base += SCAN_THREADS) {
+        int i = base + threadIdx.x;
+        int v = (i < nb) ? sums[i] : 0;
+        int tot;
+        int ex = block_excl_scan(v, wtot, tot);
+        if (i < nb) sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        sums[nb] = carry;
+        if (total) *total = carry;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const int* in, int* out, int n,
+                                                             const int* __restrict__ sums) {
+    __shared__ int wtot[SCAN_THREADS / 64];
+    // thread t owns SCAN_ITEMS consecutive elements: base + t*SCAN_ITEMS + k
+    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        long long i = base + k;
+        v[k] = (i < n) ? in[i] : 0;
+        s += v[k];
+    }
+    int tot;
+    int ex = block_excl_scan(s, wtot, tot) + sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        long long i = base + k;
+        if (i < n) out[i] = ex;
+        ex += v[k];
+    }
+}
+
+int scan_exclusive_i32(const int* in, int* out, int n, int* tmp, int* total, hipStream_t stream) {
+    if (n <= 0) {
+        if (total) PBN_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(int), stream));
+        return PBN_OK;
+    }
+    const int nb = cdiv(n, SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, stream, in, n, tmp);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, stream, tmp, nb, total);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, stream, in, out, n, tmp);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+}  // namespace pbn
+
+extern "C" const char* pbn_version(void) { return "pbnet_hip 0.1 (gfx950)"; }
+extern "C" int pbn_last_hip_error(void) { return pbn::g_last_hip_error; }

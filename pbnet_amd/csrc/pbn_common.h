@@ -1,0 +1,72 @@
+// pbn_common.h -- shared helpers for the gfx950 kernels of libpbnet_hip.so (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pbnet_hip.h"
+
+namespace pbn {
+
+constexpr int WAVE = 64;
+
+extern thread_local int g_last_hip_error;
+
+#define PBN_HIP_CHECK(expr)                                  \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) {                              \
+            pbn::g_last_hip_error = (int)_e;                 \
+            return PBN_ERR_HIP;                              \
+        }                                                    \
+    } while (0)
+
+#define PBN_LAUNCH_CHECK() PBN_HIP_CHECK(hipGetLastError())
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over a caller-provided workspace (256-byte aligned carves).
+struct Carver {
+    char* base;
+    size_t off;
+    size_t cap;
+    bool ok;
+    Carver(void* p, size_t bytes) : base((char*)p), off(0), cap(bytes), ok(true) {}
+    template <typename T>
+    T* take(size_t n) {
+        size_t start = align_up(off, 256);
+        size_t end = start + n * sizeof(T);
+        if (base != nullptr && end > cap) ok = false;
+        off = end;
+        return base ? (T*)(base + start) : (T*)nullptr;
+    }
+};
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ int wave_reduce_add(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// 64-bit finalizer (splitmix64) -> table slot
+__device__ __forceinline__ uint32_t hash64(uint64_t k) {
+    k ^= k >> 30;
+    k *= 0xbf58476d1ce4e5b9ULL;
+    k ^= k >> 27;
+    k *= 0x94d049bb133111ebULL;
+    k ^= k >> 31;
+    return (uint32_t)k;
+}
+
+// ---- device-wide exclusive scan (int32), three launches; tmp must hold cdiv(n, SCAN_TILE)+1 ints -------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 elements per block
+
+static inline size_t scan_tmp_ints(long long n) { return (size_t)cdiv(n, SCAN_TILE) + 2; }
+
+// out[i] = sum_{j<i} in[j] for i in [0,n); if total != nullptr, *total = sum of all.  in may alias out.
+int scan_exclusive_i32(const int* in, int* out, int n, int* tmp, int* total, hipStream_t stream);
+
+}  // namespace pbn
