@@ -88,6 +88,71 @@ int pbn_cal_iou_and_masklabel(const int32_t* proposals_idx, const int32_t* propo
                               float* proposals_iou, int n_instance, int n_proposal,
                               const float* mask_scores_sigmoid, float* mask_label, int mode, pbn_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Sparse-voxel backbone: coordinate hashing and kernel maps.
+ * Re-creates the coordinate-manager behaviour the reference obtains from MinkowskiEngine, an un-vendored,
+ * un-pinned third-party dependency (README.md:15-27): ME.SparseTensor construction (network/PBNet.py:117,240-247,
+ * 265-271), ME.utils.sparse_quantize (datasets/scannetv2/dataset_preprocess.py:269-272), strided / transposed
+ * coordinate maps and kernel maps behind MinkowskiConvolution(Transpose) (network/Mink.py:221-288).
+ * Coordinates are int32 rows (batch, x, y, z); batch in [0,65534], x/y/z in [-32768,32767].
+ * Hash tables are caller-owned: keys uint64[capacity], vals int32[capacity], capacity = pbn_hash_capacity(n).
+ * Data-dependent row counts are written to DEVICE ints; a count of -1 flags an out-of-range coordinate.
+ * `n_*_dev` inputs may be NULL (then the *_max value is the exact count).
+ */
+int pbn_hash_capacity(int n);
+size_t pbn_coords_workspace_bytes(int n_max);
+
+/* De-duplicate rows: first occurrence survives, survivors keep ascending original order.
+ * unique_index[n_unique] (original row of each survivor), inverse[n] (survivor id of every input row, may be NULL),
+ * unique_coords[n_unique,4] (may be NULL).  The table maps coordinate -> survivor id afterwards. */
+int pbn_coords_unique(const int32_t* coords, const int32_t* n_dev, int n_max, uint64_t* table_keys, int32_t* table_vals,
+                      int capacity, int32_t* unique_index, int32_t* inverse, int32_t* unique_coords, int32_t* n_unique,
+                      void* workspace, size_t workspace_bytes, pbn_stream_t stream);
+
+/* Coarser coordinate set floor(c / stride_out) * stride_out (first-occurrence order) of a unique fine set whose
+ * tensor stride is stride_out/2.  parent_row[n_fine], child_k[n_fine] in [0,8) (kernel index of the k=2,s=2
+ * convolution, x fastest), nbr_down[n_coarse,8] child rows (-1 = absent).  The table maps coarse coordinate -> row. */
+int pbn_coords_stride(const int32_t* fine_coords, const int32_t* n_fine_dev, int n_fine_max, int stride_out,
+                      uint64_t* table_keys, int32_t* table_vals, int capacity, int32_t* coarse_coords,
+                      int32_t* parent_row, int32_t* child_k, int32_t* nbr_down, int32_t* n_coarse, void* workspace,
+                      size_t workspace_bytes, pbn_stream_t stream);
+
+/* Output-stationary kernel map: nbr[row, k] = row of (out_coords[row] + offsets[k]) in the table, or -1.
+ * offsets int32[n_offsets,3] (already multiplied by the tensor stride). */
+int pbn_kernel_map(const int32_t* out_coords, const int32_t* n_out_dev, int n_out_max, const int32_t* offsets,
+                   int n_offsets, const uint64_t* table_keys, const int32_t* table_vals, int capacity, int32_t* nbr,
+                   pbn_stream_t stream);
+
+/* Table of the transposed k=2,s=2 convolution: nbr_up[fine_row, k] = parent row for k == child_k[fine_row], else -1. */
+int pbn_up_table(const int32_t* parent_row, const int32_t* child_k, const int32_t* n_fine_dev, int n_fine_max,
+                 int32_t* nbr_up, pbn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Sparse convolution forward (implicit GEMM on MFMA), replacing MinkowskiConvolution / MinkowskiConvolutionTranspose /
+ * MinkowskiLinear forward as used at network/Mink.py:293-350 and network/PBNet.py:43-82,121-123,249,273-277:
+ *     out[o, c] = act( (sum_k sum_ci in[nbr[o,k], ci] * W[k, ci, c]) * scale[c] + shift[c] + residual[o, c] )
+ *  in_feat   [*, ld_in]  T   input slab (pointer already advanced to the first input column); padding columns
+ *                            up to vecs_per_offset*(16/sizeof(T)) must be readable and finite
+ *  nbr       [n_out, n_offsets] i32 or NULL (identity: 1x1 convolution / linear, n_offsets must be 1)
+ *  row_perm  optional processing order (tile position p computes output row row_perm[p])
+ *  w_packed  weights in MFMA fragment order: [n_steps][cout_padded/16][64 lanes][16 bytes] where lane l of
+ *            (step s, tile t) holds W_flat[(4*s + l/16)*E + j, 16*t + l%16], j < E = 16/sizeof(T), and W_flat is
+ *            W[k, ci, c] flattened over (k, ci) with ci padded to vecs_per_offset*E; zero outside the real extent
+ *  scale/shift [cout_padded] f32 or NULL (folded eval-mode BatchNorm / bias)
+ *  residual  [*, ld_res] T or NULL;  relu != 0 applies max(.,0);  out_feat [*, ld_out] T, cout_padded columns written
+ *  dtype     PBN_F32 (v_mfma_f32_16x16x4_f32, exact fp32: the parity configuration), PBN_BF16, PBN_F16
+ *  rows_per_wave 16, 32 or 0 (auto).  fp32 accumulation, fixed summation order: results are deterministic.
+ */
+int pbn_spconv_forward(const void* in_feat, int ld_in, const int32_t* nbr, int n_offsets, const int32_t* row_perm,
+                       const int32_t* n_out_dev, int n_out, const void* w_packed, int vecs_per_offset, int n_steps,
+                       int cout_padded, const float* scale, const float* shift, const void* residual, int ld_res,
+                       int relu, void* out_feat, int ld_out, int dtype, int rows_per_wave, pbn_stream_t stream);
+
+/* out[i, :] = in[idx[i], :] on 16-byte multiples (voxel -> point gathers, network/PBNet.py:130-134,250). */
+int pbn_gather_rows(const void* in, int ld_in_bytes, const int64_t* idx, int n, int row_bytes, void* out,
+                    int ld_out_bytes, pbn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,210 @@
+"""Sparse convolution modules over libpbnet_hip.so's implicit-GEMM kernel (csrc/spconv.hip).
+
+Mirrors the constructor signatures and parameter names the reference uses from MinkowskiEngine
+(/root/reference/network/Mink.py:221-288: MinkowskiConvolution / MinkowskiConvolutionTranspose with `.kernel`
+[K^3,Cin,Cout] or [Cin,Cout] and optional `.bias` [1,Cout]; network/PBNet.py:43-82: MinkowskiLinear with `.linear`).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _native as N
+from .core import SparseTensor
+
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+_ELEMS = {torch.float32: 4, torch.bfloat16: 8, torch.float16: 8}
+
+
+def _vpo(cin, dtype):
+    e = _ELEMS[dtype]
+    v = (cin + e - 1) // e
+    return v if v in (1, 2) else (v + 3) // 4 * 4
+
+
+def pack_weight(kernel, dtype):
+    """kernel [K, Cin, Cout] (fp32 master) -> MFMA-fragment order [n_steps, cout_p/16, 64, 16 bytes] of `dtype`.
+
+    Layout contract: include/pbnet_hip.h (pbn_spconv_forward, `w_packed`)."""
+    k, cin, cout = kernel.shape
+    e = _ELEMS[dtype]
+    vpo = _vpo(cin, dtype)
+    cin_p = vpo * e
+    cout_p = (cout + 15) // 16 * 16
+    n_steps = (k * vpo + 3) // 4
+    chunk = 4 * e
+    w = torch.zeros(n_steps * chunk, cout_p, dtype=torch.float32, device=kernel.device)
+    wp = torch.zeros(k, cin_p, cout_p, dtype=torch.float32, device=kernel.device)
+    wp[:, :cin, :cout] = kernel.detach().float()
+    w[:k * cin_p] = wp.reshape(k * cin_p, cout_p)
+    # [S, g(4), j(E), T, c(16)] -> [S, T, g, c, j]
+    w = w.reshape(n_steps, 4, e, cout_p // 16, 16).permute(0, 3, 1, 4, 2).contiguous().to(dtype)
+    return w, vpo, n_steps, cout_p
+
+
+class _PackCache(object):
+    """Per-module cache of packed weights keyed by (dtype, parameter version)."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, kernel, dtype):
+        key = (dtype, kernel._version, kernel.data_ptr(), kernel.device)
+        hit = self.store.get(dtype)
+        if hit is None or hit[0] != key:
+            k3 = kernel if kernel.dim() == 3 else kernel.unsqueeze(0)
+            hit = (key, pack_weight(k3, dtype))
+            self.store[dtype] = hit
+        return hit[1]
+
+    def get_linear(self, weight, dtype):
+        """nn.Linear weight [out, in] -> packed [1, in, out]."""
+        key = (dtype, weight._version, weight.data_ptr(), weight.device)
+        hit = self.store.get(dtype)
+        if hit is None or hit[0] != key:
+            hit = (key, pack_weight(weight.detach().t().unsqueeze(0), dtype))
+            self.store[dtype] = hit
+        return hit[1]
+
+
+def spconv_forward(feats, nbr, n_out, packed, scale=None, shift=None, residual=None, relu=False, out=None,
+                   row_perm=None, rows_per_wave=0):
+    """Launch pbn_spconv_forward.  feats [n_in, C] (row stride = feats.stride(0)), nbr int32 [n_out, K] or None.
+
+    Returns the output slab view [n_out, cout_p] (writes into `out` when given: a [n_out, >=cout_p] strided view)."""
+    w, vpo, n_steps, cout_p = packed
+    dtype = feats.dtype
+    e = _ELEMS[dtype]
+    cin_p = vpo * e
+    assert feats.stride(1) == 1
+    if feats.shape[1] < cin_p or (feats.stride(0) * feats.element_size()) % 16 or feats.data_ptr() % 16:
+        padded = torch.zeros(feats.shape[0], cin_p, dtype=dtype, device=feats.device)
+        padded[:, :feats.shape[1]] = feats
+        feats = padded
+    k = 1 if nbr is None else int(nbr.shape[1])
+    assert n_steps == (k * vpo + 3) // 4, "packed weight does not match the kernel map"
+    if out is None:
+        out = torch.empty(n_out, cout_p, dtype=dtype, device=feats.device)
+    assert out.stride(1) == 1 and out.shape[1] >= cout_p and out.dtype == dtype
+    if residual is not None:
+        assert residual.stride(1) == 1 and residual.dtype == dtype and residual.shape[1] >= cout_p
+    rc = N.lib().pbn_spconv_forward(
+        N.c_vp(feats.data_ptr()), feats.stride(0), None if nbr is None else N.c_vp(nbr.data_ptr()), k,
+        None if row_perm is None else N.c_vp(row_perm.data_ptr()), None, int(n_out), N.c_vp(w.data_ptr()), vpo, n_steps,
+        cout_p, None if scale is None else N.c_vp(scale.data_ptr()), None if shift is None else N.c_vp(shift.data_ptr()),
+        None if residual is None else N.c_vp(residual.data_ptr()), 0 if residual is None else residual.stride(0),
+        int(bool(relu)), N.c_vp(out.data_ptr()), out.stride(0), _DT[dtype], int(rows_per_wave), N.current_stream())
+    N.check(rc, "pbn_spconv_forward")
+    return out
+
+
+def _pad_vec(v, cout_p, fill):
+    out = torch.full((cout_p,), fill, dtype=torch.float32, device=v.device)
+    out[:v.numel()] = v.reshape(-1).float()
+    return out
+
+
+class _ConvFn(torch.autograd.Function):
+    """Forward only for now; the backward kernels (dgrad / wgrad) are the training row of SURVEY 8f."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel, bias, nbr, n_out, cache):
+        packed = cache.get(kernel, feats.dtype)
+        shift = None if bias is None else _pad_vec(bias, packed[3], 0.0)
+        out = spconv_forward(feats, nbr, n_out, packed, shift=shift)
+        cout = kernel.shape[-1]
+        return out if out.shape[1] == cout else out[:, :cout]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        raise NotImplementedError("sparse convolution backward is not built yet (training row, DESIGN.md)")
+
+
+class MinkowskiConvolutionBase(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, is_transpose=False, dimension=None):
+        super().__init__()
+        assert dimension in (None, 3), "only 3-D sparse tensors are on the path"
+        assert dilation == 1
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.is_transpose = int(kernel_size), int(stride), is_transpose
+        self.kernel_volume = self.kernel_size ** 3
+        self.use_mm = (self.kernel_volume == 1 and self.stride == 1)  # ME: plain matmul, kernel [Cin, Cout]
+        shape = (in_channels, out_channels) if self.use_mm else (self.kernel_volume, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(*shape))
+        self.bias = nn.Parameter(torch.empty(1, out_channels)) if bias else None
+        self._cache = _PackCache()
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # ME's default: uniform(-1/sqrt(n), 1/sqrt(n)), n = (out if transposed else in) * kernel_volume
+        with torch.no_grad():
+            n = (self.out_channels if self.is_transpose else self.in_channels) * self.kernel_volume
+            stdv = 1.0 / math.sqrt(n)
+            self.kernel.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def _map(self, x):
+        cm, s = x.coordinate_manager, x.tensor_stride
+        if self.is_transpose:
+            assert self.kernel_size == 2 and self.stride == 2, "only k=2,s=2 transposed convolutions are on the path"
+            return cm.up_map(s), s // 2
+        if self.kernel_size == 1 and self.stride == 1:
+            return None, s
+        if self.stride == 2:
+            assert self.kernel_size == 2, "only k=2,s=2 strided convolutions are on the path"
+            return cm.down_map(s), s * 2
+        assert self.stride == 1 and self.kernel_size % 2 == 1
+        return cm.kernel_map(s, self.kernel_size), s
+
+    def forward(self, x):
+        nbr, out_stride = self._map(x)
+        n_out = x.coordinate_manager.num_rows(out_stride)
+        feats = _ConvFn.apply(x.F, self.kernel, self.bias, nbr, n_out, self._cache)
+        return SparseTensor(feats, coordinate_manager=x.coordinate_manager, tensor_stride=out_stride)
+
+    def extra_repr(self):
+        return "in=%d, out=%d, kernel_size=%d, stride=%d%s" % (self.in_channels, self.out_channels, self.kernel_size,
+                                                                self.stride, ", transposed" if self.is_transpose else "")
+
+
+class MinkowskiConvolution(MinkowskiConvolutionBase):
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, dimension=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride, dilation, bias, kernel_generator, False,
+                         dimension)
+
+
+class MinkowskiConvolutionTranspose(MinkowskiConvolutionBase):
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, dimension=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride, dilation, bias, kernel_generator, True,
+                         dimension)
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, weight, bias, cache):
+        packed = cache.get_linear(weight, feats.dtype)
+        shift = None if bias is None else _pad_vec(bias, packed[3], 0.0)
+        out = spconv_forward(feats, None, feats.shape[0], packed, shift=shift)
+        cout = weight.shape[0]
+        return out if out.shape[1] == cout else out[:, :cout]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        raise NotImplementedError("linear backward through the HIP path is not built yet")
+
+
+class MinkowskiLinear(nn.Module):
+    """ME.MinkowskiLinear: `self.linear = nn.Linear` on the feature matrix (state-dict key `linear.weight`)."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+        self._cache = _PackCache()
+
+    def forward(self, x):
+        feats = _LinearFn.apply(x.F, self.linear.weight, self.linear.bias, self._cache)
+        return x.replace_feature(feats)

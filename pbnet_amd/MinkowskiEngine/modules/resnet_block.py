@@ -1,0 +1,42 @@
+"""MinkowskiEngine.modules.resnet_block.BasicBlock (imported by the reference at network/Mink.py:11)."""
+import torch.nn as nn
+
+from ..conv import MinkowskiConvolution
+from ..nn import MinkowskiBatchNorm, MinkowskiReLU
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, bn_momentum=0.1, dimension=-1):
+        super().__init__()
+        assert dimension > 0
+        self.conv1 = MinkowskiConvolution(inplanes, planes, kernel_size=3, stride=stride, dilation=dilation,
+                                          dimension=dimension)
+        self.norm1 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.conv2 = MinkowskiConvolution(planes, planes, kernel_size=3, stride=1, dilation=dilation,
+                                          dimension=dimension)
+        self.norm2 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.relu = MinkowskiReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        residual = x
+        out = self.conv1(x)
+        out = self.norm1(out)
+        out = self.relu(out)
+        out = self.conv2(out)
+        out = self.norm2(out)
+        if self.downsample is not None:
+            residual = self.downsample(x)
+        out = out.replace_feature(out.F + residual.F)
+        out = self.relu(out)
+        return out
+
+
+class Bottleneck(nn.Module):
+    """Present in ME and imported by Mink.py:11, but no reachable network uses it."""
+    expansion = 4
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("Bottleneck networks are never instantiated by PBNet (SURVEY.md section 2 #1)")

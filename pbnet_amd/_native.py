@@ -28,6 +28,17 @@ SIGNATURES = {
     "pbn_get_iou": (c_int, [c_i32p, c_i32p, c_vp, c_i32p, c_f32p, c_int, c_int, c_vp]),
     "pbn_cal_iou_and_masklabel": (c_int, [c_i32p, c_i32p, c_vp, c_i32p, c_f32p, c_int, c_int, c_f32p, c_f32p, c_int,
                                           c_vp]),
+    "pbn_hash_capacity": (c_int, [c_int]),
+    "pbn_coords_workspace_bytes": (c_size, [c_int]),
+    "pbn_coords_unique": (c_int, [c_i32p, c_i32p, c_int, c_vp, c_i32p, c_int, c_i32p, c_i32p, c_i32p, c_i32p, c_vp,
+                                  c_size, c_vp]),
+    "pbn_coords_stride": (c_int, [c_i32p, c_i32p, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_i32p, c_i32p, c_i32p,
+                                  c_i32p, c_vp, c_size, c_vp]),
+    "pbn_kernel_map": (c_int, [c_i32p, c_i32p, c_int, c_i32p, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
+    "pbn_up_table": (c_int, [c_i32p, c_i32p, c_i32p, c_int, c_i32p, c_vp]),
+    "pbn_spconv_forward": (c_int, [c_vp, c_int, c_i32p, c_int, c_i32p, c_i32p, c_int, c_vp, c_int, c_int, c_int,
+                                   c_f32p, c_f32p, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp]),
+    "pbn_gather_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
 }
 
 ERRORS = {-1: "PBN_ERR_ARG", -2: "PBN_ERR_WORKSPACE", -3: "PBN_ERR_HIP", -4: "PBN_ERR_RANGE", -5: "PBN_ERR_UNSUPPORTED"}

@@ -1,0 +1,303 @@
+// coords.hip -- COO coordinate hashing for the sparse-voxel backbone on gfx950.
+//
+// Re-creates (does not port) the coordinate-manager behaviour the reference obtains from MinkowskiEngine
+// (/root/reference/network/PBNet.py:117,240-247,265-271; network/Mink.py:221-288; dataset_preprocess.py:269-272):
+//   * voxelisation / de-duplication with first-occurrence winner and ascending survivor order + inverse map,
+//   * strided coordinate sets floor(c/s)*s with child->parent map and the 8-way child table of k=2,s=2 convs,
+//   * kernel maps ("rulebooks") as OUTPUT-STATIONARY neighbour tables nbr[row][k] = input row or -1, which is what
+//     the gather-GEMM kernels in spconv.hip consume (no scatter, no atomics on features, deterministic sums).
+//
+// Keys: (batch:16 | x+2^15:16 | y+2^15:16 | z+2^15:16) in one 64-bit word; open addressing, linear probing,
+// capacity = pow2 >= 2n.  Values: smallest inserting row (atomicMin) => deterministic "first occurrence".
+// Row counts that depend on the data stay on the DEVICE (n_out pointers); kernels take an upper bound for the grid
+// and read the real count, so a whole coordinate pyramid is built without a host round trip.
+#include "pbn_common.h"
+
+namespace pbn {
+namespace {
+
+constexpr int TPB = 256;
+constexpr unsigned long long EMPTY_KEY = ~0ULL;
+
+__device__ __forceinline__ bool in_range(int b, int x, int y, int z) {
+    return b >= 0 && b < 65535 && x >= -32768 && x <= 32767 && y >= -32768 && y <= 32767 && z >= -32768 && z <= 32767;
+}
+
+__device__ __forceinline__ unsigned long long pack4(int b, int x, int y, int z) {
+    return ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)(unsigned)((x + 32768) & 0xffff) << 32) |
+           ((unsigned long long)(unsigned)((y + 32768) & 0xffff) << 16) | (unsigned long long)(unsigned)((z + 32768) & 0xffff);
+}
+
+__device__ __forceinline__ int floor_div(int a, int s) {  // s > 0
+    int q = a / s;
+    return (a % s != 0 && a < 0) ? q - 1 : q;
+}
+
+__device__ __forceinline__ int table_insert_min(unsigned long long* __restrict__ keys, int* __restrict__ vals,
+                                                unsigned mask, unsigned long long key, int row) {
+    unsigned h = hash64(key) & mask;
+    while (true) {
+        unsigned long long prev = atomicCAS(&keys[h], EMPTY_KEY, key);
+        if (prev == EMPTY_KEY || prev == key) break;
+        h = (h + 1) & mask;
+    }
+    atomicMin(&vals[h], row);
+    return (int)h;
+}
+
+__device__ __forceinline__ int table_find(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
+                                          unsigned mask, unsigned long long key) {
+    unsigned h = hash64(key) & mask;
+    while (true) {
+        const unsigned long long k = keys[h];
+        if (k == key) return vals[h];
+        if (k == EMPTY_KEY) return -1;
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ int real_n(const int* n_dev, int n_max) {
+    if (!n_dev) return n_max;
+    const int v = *n_dev;
+    return v < n_max ? v : n_max;
+}
+
+// ---- unique ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_insert_rows(const int* __restrict__ coords, const int* n_dev, int n_max,
+                                                    unsigned long long* __restrict__ keys, int* __restrict__ vals,
+                                                    unsigned mask, int* __restrict__ slot_of_row, int* __restrict__ status) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= real_n(n_dev, n_max)) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    if (!in_range(c.x, c.y, c.z, c.w)) atomicOr(status, 1);
+    slot_of_row[i] = table_insert_min(keys, vals, mask, pack4(c.x, c.y, c.z, c.w), i);
+}
+
+__global__ __launch_bounds__(TPB) void k_first_flags(const int* __restrict__ slot_of_row, const int* __restrict__ vals,
+                                                    const int* n_dev, int n_max, int* __restrict__ flags) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n_max) return;
+    flags[i] = (i < real_n(n_dev, n_max) && vals[slot_of_row[i]] == i) ? 1 : 0;
+}
+
+// unique_index[new] = first row; inverse[i] = new id of i's survivor
+__global__ __launch_bounds__(TPB) void k_unique_write(const int* __restrict__ slot_of_row, const int* __restrict__ vals,
+                                                     const int* __restrict__ flags, const int* __restrict__ newid,
+                                                     const int* n_dev, int n_max, int* __restrict__ unique_index,
+                                                     int* __restrict__ inverse) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= real_n(n_dev, n_max)) return;
+    if (flags[i]) unique_index[newid[i]] = i;
+    if (inverse) inverse[i] = newid[vals[slot_of_row[i]]];
+}
+
+// table values: first original row -> row id in the de-duplicated set (only slots owned by a first row)
+__global__ __launch_bounds__(TPB) void k_table_renumber(const int* __restrict__ slot_of_row, const int* __restrict__ flags,
+                                                       const int* __restrict__ newid, const int* n_dev, int n_max,
+                                                       int* __restrict__ vals) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= real_n(n_dev, n_max)) return;
+    if (flags[i]) vals[slot_of_row[i]] = newid[i];
+}
+
+__global__ __launch_bounds__(TPB) void k_gather_coords(const int* __restrict__ coords, const int* __restrict__ unique_index,
+                                                      const int* __restrict__ n_unique, int n_max,
+                                                      int* __restrict__ out_coords) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= real_n(n_unique, n_max)) return;
+    reinterpret_cast<int4*>(out_coords)[i] = reinterpret_cast<const int4*>(coords)[unique_index[i]];
+}
+
+// ---- stride: parent coordinate of every fine row ------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_insert_parents(const int* __restrict__ coords, const int* n_dev, int n_max,
+                                                       int stride_out, unsigned long long* __restrict__ keys,
+                                                       int* __restrict__ vals, unsigned mask,
+                                                       int* __restrict__ slot_of_row) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= real_n(n_dev, n_max)) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    const int px = floor_div(c.y, stride_out) * stride_out, py = floor_div(c.z, stride_out) * stride_out,
+              pz = floor_div(c.w, stride_out) * stride_out;
+    slot_of_row[i] = table_insert_min(keys, vals, mask, pack4(c.x, px, py, pz), i);
+}
+
+// coarse coords (first-occurrence order), child -> (parent row, k), 8-way child table of the k=2,s=2 convolution
+__global__ __launch_bounds__(TPB) void k_stride_write(const int* __restrict__ coords, const int* n_dev, int n_max,
+                                                     int stride_out, const int* __restrict__ slot_of_row,
+                                                     const int* __restrict__ vals, const int* __restrict__ flags,
+                                                     const int* __restrict__ newid, int* __restrict__ coarse_coords,
+                                                     int* __restrict__ parent_row, int* __restrict__ child_k,
+                                                     int* __restrict__ nbr_down) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= real_n(n_dev, n_max)) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    const int s_in = stride_out >> 1;
+    const int px = floor_div(c.y, stride_out) * stride_out, py = floor_div(c.z, stride_out) * stride_out,
+              pz = floor_div(c.w, stride_out) * stride_out;
+    const int first = vals[slot_of_row[i]];  // still the first child row here
+    const int prow = newid[first];
+    if (flags[i]) reinterpret_cast<int4*>(coarse_coords)[prow] = make_int4(c.x, px, py, pz);
+    // even kernel (K=2): offsets 0..1 per axis, x fastest (ME convention C1/C2)
+    const int k = ((c.y - px) / s_in) + 2 * ((c.z - py) / s_in) + 4 * ((c.w - pz) / s_in);
+    parent_row[i] = prow;
+    child_k[i] = k;
+    nbr_down[(size_t)prow * 8 + k] = i;
+}
+
+// ---- kernel map: nbr[row][k] = row of (coords[row] + offsets[k]) in the table, or -1 -----------------------------
+__global__ __launch_bounds__(TPB) void k_kernel_map(const int* __restrict__ out_coords, const int* n_dev, int n_max,
+                                                   const int* __restrict__ offsets, int K,
+                                                   const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
+                                                   unsigned mask, int* __restrict__ nbr) {
+    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+    const int n = real_n(n_dev, n_max);
+    if (e >= (long long)n * K) return;
+    const int row = (int)(e / K), k = (int)(e % K);
+    const int4 c = reinterpret_cast<const int4*>(out_coords)[row];
+    const int x = c.y + offsets[3 * k + 0], y = c.z + offsets[3 * k + 1], z = c.w + offsets[3 * k + 2];
+    int r = -1;
+    if (in_range(c.x, x, y, z)) r = table_find(keys, vals, mask, pack4(c.x, x, y, z));
+    nbr[e] = r;
+}
+
+// up-conv (transposed k=2,s=2) table: fine row -> nbr_up[row][k] = parent row at k = child_k[row], -1 elsewhere
+__global__ __launch_bounds__(TPB) void k_up_table(const int* __restrict__ parent_row, const int* __restrict__ child_k,
+                                                 const int* n_dev, int n_max, int* __restrict__ nbr_up) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= real_n(n_dev, n_max)) return;
+    const int k = child_k[i], p = parent_row[i];
+    int4 lo = make_int4(-1, -1, -1, -1), hi = lo;
+    int* v = (k < 4) ? &lo.x : &hi.x;
+    v[k & 3] = p;
+    reinterpret_cast<int4*>(nbr_up)[2 * (size_t)i + 0] = lo;
+    reinterpret_cast<int4*>(nbr_up)[2 * (size_t)i + 1] = hi;
+}
+
+__global__ void k_set_status(const int* __restrict__ status, int* __restrict__ n_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && *status != 0) *n_out = -1;
+}
+
+}  // namespace
+}  // namespace pbn
+
+using namespace pbn;
+
+extern "C" int pbn_hash_capacity(int n) {
+    unsigned c = 1024;
+    while (c < 2u * (unsigned)(n > 0 ? n : 0)) c <<= 1;
+    return (int)c;
+}
+
+extern "C" size_t pbn_coords_workspace_bytes(int n_max) {
+    const size_t N = (size_t)(n_max > 0 ? n_max : 1);
+    return 3 * align_up(N * sizeof(int), 256) + align_up(scan_tmp_ints((long long)N) * sizeof(int), 256) + 512;
+}
+
+namespace {
+struct CoordWs {
+    int *slot_of_row, *flags, *newid, *scan_tmp, *status;
+};
+bool carve_ws(void* ws, size_t bytes, int n_max, CoordWs& w) {
+    Carver cv(ws, bytes);
+    const size_t N = (size_t)(n_max > 0 ? n_max : 1);
+    w.slot_of_row = cv.take<int>(N);
+    w.flags = cv.take<int>(N);
+    w.newid = cv.take<int>(N);
+    w.scan_tmp = cv.take<int>(scan_tmp_ints((long long)N));
+    w.status = cv.take<int>(4);
+    return cv.ok;
+}
+}  // namespace
+
+extern "C" int pbn_coords_unique(const int32_t* coords, const int32_t* n_dev, int n_max, uint64_t* table_keys,
+                                 int32_t* table_vals, int capacity, int32_t* unique_index, int32_t* inverse,
+                                 int32_t* unique_coords, int32_t* n_unique, void* workspace, size_t workspace_bytes,
+                                 pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_max < 0 || capacity < 1024 || (capacity & (capacity - 1)) || (long long)capacity < 2LL * n_max || !n_unique ||
+        !table_keys || !table_vals)
+        return PBN_ERR_ARG;
+    PBN_HIP_CHECK(hipMemsetAsync(table_keys, 0xff, sizeof(uint64_t) * (size_t)capacity, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(table_vals, 0x7f, sizeof(int) * (size_t)capacity, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(n_unique, 0, sizeof(int), stream));
+    if (n_max == 0) return PBN_OK;
+    if (!coords || !unique_index || !workspace) return PBN_ERR_ARG;
+    CoordWs w;
+    if (!carve_ws(workspace, workspace_bytes, n_max, w)) return PBN_ERR_WORKSPACE;
+    PBN_HIP_CHECK(hipMemsetAsync(w.status, 0, sizeof(int) * 4, stream));
+    const int nb = cdiv(n_max, TPB);
+    const unsigned mask = (unsigned)capacity - 1;
+    hipLaunchKernelGGL(k_insert_rows, dim3(nb), dim3(TPB), 0, stream, coords, n_dev, n_max,
+                       (unsigned long long*)table_keys, table_vals, mask, w.slot_of_row, w.status);
+    hipLaunchKernelGGL(k_first_flags, dim3(nb), dim3(TPB), 0, stream, w.slot_of_row, table_vals, n_dev, n_max, w.flags);
+    int rc = scan_exclusive_i32(w.flags, w.newid, n_max, w.scan_tmp, n_unique, stream);
+    if (rc != PBN_OK) return rc;
+    hipLaunchKernelGGL(k_unique_write, dim3(nb), dim3(TPB), 0, stream, w.slot_of_row, table_vals, w.flags, w.newid, n_dev,
+                       n_max, unique_index, inverse);
+    hipLaunchKernelGGL(k_table_renumber, dim3(nb), dim3(TPB), 0, stream, w.slot_of_row, w.flags, w.newid, n_dev, n_max,
+                       table_vals);
+    if (unique_coords)
+        hipLaunchKernelGGL(k_gather_coords, dim3(nb), dim3(TPB), 0, stream, coords, unique_index, n_unique, n_max,
+                           unique_coords);
+    hipLaunchKernelGGL(k_set_status, dim3(1), dim3(64), 0, stream, w.status, n_unique);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_coords_stride(const int32_t* fine_coords, const int32_t* n_fine_dev, int n_fine_max, int stride_out,
+                                 uint64_t* table_keys, int32_t* table_vals, int capacity, int32_t* coarse_coords,
+                                 int32_t* parent_row, int32_t* child_k, int32_t* nbr_down, int32_t* n_coarse,
+                                 void* workspace, size_t workspace_bytes, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_fine_max < 0 || stride_out < 2 || (stride_out & 1) || capacity < 1024 || (capacity & (capacity - 1)) ||
+        (long long)capacity < 2LL * n_fine_max || !n_coarse || !table_keys || !table_vals)
+        return PBN_ERR_ARG;
+    PBN_HIP_CHECK(hipMemsetAsync(table_keys, 0xff, sizeof(uint64_t) * (size_t)capacity, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(table_vals, 0x7f, sizeof(int) * (size_t)capacity, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(n_coarse, 0, sizeof(int), stream));
+    if (n_fine_max == 0) return PBN_OK;
+    if (!fine_coords || !coarse_coords || !parent_row || !child_k || !nbr_down || !workspace) return PBN_ERR_ARG;
+    CoordWs w;
+    if (!carve_ws(workspace, workspace_bytes, n_fine_max, w)) return PBN_ERR_WORKSPACE;
+    PBN_HIP_CHECK(hipMemsetAsync(nbr_down, 0xff, sizeof(int) * 8 * (size_t)n_fine_max, stream));
+    const int nb = cdiv(n_fine_max, TPB);
+    const unsigned mask = (unsigned)capacity - 1;
+    hipLaunchKernelGGL(k_insert_parents, dim3(nb), dim3(TPB), 0, stream, fine_coords, n_fine_dev, n_fine_max, stride_out,
+                       (unsigned long long*)table_keys, table_vals, mask, w.slot_of_row);
+    hipLaunchKernelGGL(k_first_flags, dim3(nb), dim3(TPB), 0, stream, w.slot_of_row, table_vals, n_fine_dev, n_fine_max,
+                       w.flags);
+    int rc = scan_exclusive_i32(w.flags, w.newid, n_fine_max, w.scan_tmp, n_coarse, stream);
+    if (rc != PBN_OK) return rc;
+    hipLaunchKernelGGL(k_stride_write, dim3(nb), dim3(TPB), 0, stream, fine_coords, n_fine_dev, n_fine_max, stride_out,
+                       w.slot_of_row, table_vals, w.flags, w.newid, coarse_coords, parent_row, child_k, nbr_down);
+    hipLaunchKernelGGL(k_table_renumber, dim3(nb), dim3(TPB), 0, stream, w.slot_of_row, w.flags, w.newid, n_fine_dev,
+                       n_fine_max, table_vals);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_kernel_map(const int32_t* out_coords, const int32_t* n_out_dev, int n_out_max, const int32_t* offsets,
+                              int n_offsets, const uint64_t* table_keys, const int32_t* table_vals, int capacity,
+                              int32_t* nbr, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_out_max < 0 || n_offsets < 1 || capacity < 1024 || (capacity & (capacity - 1))) return PBN_ERR_ARG;
+    if (n_out_max == 0) return PBN_OK;
+    if (!out_coords || !offsets || !table_keys || !table_vals || !nbr) return PBN_ERR_ARG;
+    const long long total = (long long)n_out_max * n_offsets;
+    hipLaunchKernelGGL(k_kernel_map, dim3(cdiv(total, TPB)), dim3(TPB), 0, stream, out_coords, n_out_dev, n_out_max,
+                       offsets, n_offsets, (const unsigned long long*)table_keys, table_vals, (unsigned)capacity - 1, nbr);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_up_table(const int32_t* parent_row, const int32_t* child_k, const int32_t* n_fine_dev, int n_fine_max,
+                            int32_t* nbr_up, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_fine_max < 0) return PBN_ERR_ARG;
+    if (n_fine_max == 0) return PBN_OK;
+    if (!parent_row || !child_k || !nbr_up) return PBN_ERR_ARG;
+    hipLaunchKernelGGL(k_up_table, dim3(cdiv(n_fine_max, TPB)), dim3(TPB), 0, stream, parent_row, child_k, n_fine_dev,
+                       n_fine_max, nbr_up);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}

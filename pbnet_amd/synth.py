@@ -46,8 +46,8 @@ def synth_room(seed=2, pitch=0.0225, room=(4.0, 3.2, 2.6), n_boxes=12):
     add((X, 0, 0), Y * ey, Z * ez, -ex, 1, -100)
     for j in range(n_boxes):
         sx, sy, sz = rng.uniform(0.4, 1.6), rng.uniform(0.4, 0.9), rng.uniform(0.4, 1.1)
-        sx, sy = min(sx, 0.8 * X), min(sy, 0.8 * Y)
-        ox, oy = rng.uniform(0.05, X - sx - 0.05), rng.uniform(0.05, Y - sy - 0.05)
+        sx, sy, sz = min(sx, 0.6 * X), min(sy, 0.6 * Y), min(sz, 0.8 * Z)
+        ox, oy = rng.uniform(0.05 * X, 0.95 * X - sx), rng.uniform(0.05 * Y, 0.95 * Y - sy)
         o = np.array([ox, oy, 0.0])
         sem = 2 + (j % 18)
         add(o + sz * ez, sx * ex, sy * ey, ez, sem, j)                # top

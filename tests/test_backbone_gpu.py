@@ -1,0 +1,234 @@
+"""GPU tier: sparse-voxel backbone (coords.hip + spconv.hip through the C ABI) against the CPU oracle
+(oracle/sparse_ref.py) and the committed golden fixtures.  Tolerance: 1e-4 absolute on fp32 features
+(BASELINE.json north_star); bf16/f16 slabs are checked against the fp32 result with a dtype-sized tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_ref as R
+import pbnet_amd.MinkowskiEngine as ME
+from pbnet_amd import synth
+from pbnet_amd.network.Mink import Mink_unet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def _scene_coords(seed, room=(0.6, 0.5, 0.4), n_boxes=1, batch=2):
+    sc = synth.synth_room(seed=seed, pitch=0.0225, room=room, n_boxes=n_boxes)
+    q, _, _ = synth.voxelize_numpy(sc["xyz"], 0.02)
+    parts = []
+    for b in range(batch):
+        c = np.concatenate([np.full((len(q), 1), b, np.int32), q + np.array([5 * b, -3 * b, b], np.int32)], 1)
+        parts.append(c[: len(c) if b == 0 else len(c) // 2])
+    return np.concatenate(parts, 0).astype(np.int32)
+
+
+def test_coordinate_pyramid_matches_oracle():
+    coords = _scene_coords(41)
+    cm_ref = R.CoordinateManager(coords)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(DEV))
+    for s in (1, 2, 4, 8, 16):
+        want = cm_ref.get_coords(s)
+        got = cm.coordinates(s).cpu().numpy()
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), "stride %d coordinates / first-occurrence order" % s
+    # kernel maps: same (in,out) pair sets as the oracle's per-offset maps
+    for s, k in ((1, 3), (2, 3), (8, 3), (1, 5)):
+        nbr = cm.kernel_map(s, k).cpu().numpy()
+        maps = cm_ref.get_map(s, s, k)
+        assert nbr.shape[1] == k ** 3
+        for kk, (in_rows, out_rows) in enumerate(maps):
+            col = nbr[:, kk]
+            assert np.array_equal(np.nonzero(col >= 0)[0], out_rows)
+            assert np.array_equal(col[out_rows], in_rows)
+    # strided maps: every fine row appears exactly once in its parent's child table at its own k
+    for s in (1, 2, 4, 8):
+        down = cm.down_map(s).cpu().numpy()
+        up = cm.up_map(2 * s).cpu().numpy()
+        maps = cm_ref.get_map(s, 2 * s, 2)
+        for kk, (fine_rows, coarse_rows) in enumerate(maps):
+            assert np.array_equal(down[coarse_rows, kk], fine_rows)
+            assert np.array_equal(up[fine_rows, kk], coarse_rows)
+        assert (up >= 0).sum() == cm.num_rows(s) and (down >= 0).sum() == cm.num_rows(s)
+
+
+def test_duplicate_coordinates_first_occurrence():
+    """B5: ME.SparseTensor dedupe + inverse_mapping (PBNet.py:240-247) and sparse_quantize."""
+    rng = np.random.default_rng(0)
+    base = rng.integers(-20, 20, (500, 3)).astype(np.int32)
+    coords = np.concatenate([np.zeros((1500, 1), np.int32), base[rng.integers(0, 500, 1500)]], 1)
+    feats = torch.randn(1500, 8)
+    st = ME.SparseTensor(feats, torch.from_numpy(coords), device=DEV)
+    f_ref, c_ref, inv_ref = R.sparse_tensor(feats, coords)
+    assert np.array_equal(st.C.cpu().numpy(), c_ref)
+    assert torch.equal(st.F.cpu(), f_ref)
+    assert torch.equal(st.inverse_mapping.cpu(), inv_ref)
+    # unique input keeps its order
+    st2 = ME.SparseTensor(f_ref, torch.from_numpy(c_ref), device=DEV)
+    assert np.array_equal(st2.C.cpu().numpy(), c_ref) and torch.equal(st2.inverse_mapping.cpu(), torch.arange(len(c_ref)))
+    # sparse_quantize on raw points (dataset_preprocess.py:269-272)
+    xyz = rng.uniform(-1, 3, (4000, 3))
+    pf = rng.normal(size=(4000, 6)).astype(np.float32)
+    qc, qf, idx, inv = ME.utils.sparse_quantize(xyz, pf, quantization_size=0.02, return_index=True, return_inverse=True)
+    rc, rf, ridx, rinv = R.sparse_quantize(xyz, pf, 0.02)
+    assert np.array_equal(qc, rc) and np.array_equal(qf, rf) and np.array_equal(idx, ridx) and np.array_equal(inv, rinv)
+    # out-of-range coordinates are reported, not wrapped
+    bad = torch.tensor([[0, 0, 0, 0], [0, 40000, 0, 0]], dtype=torch.int32)
+    with pytest.raises(ValueError):
+        ME.SparseTensor(torch.zeros(2, 4), bad, device=DEV)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL), (torch.bfloat16, 6e-2), (torch.float16, 1e-2)])
+@pytest.mark.parametrize("cin,cout,k", [(32, 32, 3), (6, 32, 5), (96, 96, 3), (128, 256, 3), (384, 256, 3), (34, 32, 5),
+                                        (256, 256, 1), (32, 16, 1), (16, 20, 1)])
+def test_single_convolution(dtype, tol, cin, cout, k):
+    """B1: one convolution = oracle gather-mm-index_add (both kernel tile shapes)."""
+    coords = _scene_coords(43, batch=1)
+    torch.manual_seed(cin * 1000 + cout + k)
+    feats = torch.randn(len(coords), cin)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=k, bias=(k == 1), dimension=3)
+    cm_ref = R.CoordinateManager(coords)
+    want = R.conv(feats, conv.kernel.detach(), None if k == 1 else cm_ref.get_map(1, 1, k), len(coords),
+                  bias=conv.bias.detach() if conv.bias is not None else None)
+    conv = conv.to(DEV)
+    x = ME.SparseTensor(feats.to(dtype), torch.from_numpy(coords), device=DEV)
+    with torch.no_grad():
+        got = conv(x).F.float().cpu()
+    scale = want.abs().max().item()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= tol * max(scale, 1.0)
+    if dtype == torch.float32 and k == 3:
+        # explicit tile shapes: 16 and 32 rows per wave
+        from pbnet_amd.MinkowskiEngine.conv import spconv_forward
+        packed = conv._cache.get(conv.kernel, dtype)
+        nbr = x.coordinate_manager.kernel_map(1, 3)
+        for rw in (16, 32):
+            o = spconv_forward(x.F, nbr, len(coords), packed, rows_per_wave=rw)[:, :cout].cpu()
+            assert (o - want).abs().max().item() <= TOL * max(scale, 1.0)
+
+
+def test_down_up_round_trip():
+    """B2: k2s2 down then transposed up lands on the original coordinates; values equal the oracle's."""
+    coords = _scene_coords(44)
+    torch.manual_seed(3)
+    feats = torch.randn(len(coords), 32)
+    down = ME.MinkowskiConvolution(32, 64, kernel_size=2, stride=2, dimension=3)
+    up = ME.MinkowskiConvolutionTranspose(64, 32, kernel_size=2, stride=2, dimension=3)
+    cm_ref = R.CoordinateManager(coords)
+    m = cm_ref.get_map(1, 2, 2)
+    mid = R.conv(feats, down.kernel.detach(), m, cm_ref.get_coords(2).shape[0])
+    want = R.conv_transpose(mid, up.kernel.detach(), m, len(coords))
+    x = ME.SparseTensor(feats, torch.from_numpy(coords), device=DEV)
+    with torch.no_grad():
+        y = down.to(DEV)(x)
+        z = up.to(DEV)(y)
+    assert y.tensor_stride == 2 and z.tensor_stride == 1
+    assert (y.F.cpu() - mid).abs().max().item() <= TOL * max(1.0, mid.abs().max().item())
+    assert (z.F.cpu() - want).abs().max().item() <= TOL * max(1.0, want.abs().max().item())
+    assert np.array_equal(z.C.cpu().numpy(), coords)
+
+
+@pytest.mark.parametrize("arch", ["MinkUNet14A", "MinkUNet34C"])
+def test_unet_matches_golden_and_oracle(arch, golden_dir):
+    """B3/B4: whole U-Net, seeded weights, eval-mode BN (fused and module paths) and train-mode BN (module path)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_backbone_golden as G
+    g = dict(np.load(os.path.join(golden_dir, "backbone_%s.npz" % arch)))
+    cin = g["feats"].shape[1]
+    m = G.build(arch, cin)
+    feats = torch.from_numpy(g["feats"])
+    coords = g["coords"]
+    same_torch = str(g["torch_version"]) == torch.__version__
+    want_eval = torch.from_numpy(g["out_eval"]) if same_torch else R.minkunet_forward(m.state_dict(), arch, feats, coords)
+    want_train = (torch.from_numpy(g["out_train"]) if same_torch
+                  else R.minkunet_forward(m.state_dict(), arch, feats, coords, training=True))
+    m = m.to(DEV)
+    x = ME.SparseTensor(feats, torch.from_numpy(coords), device=DEV)
+    # level sizes and rule-pair counts
+    cm = x.coordinate_manager
+    assert [cm.num_rows(s) for s in (1, 2, 4, 8, 16)] == g["counts"].tolist()
+    assert [int((cm.kernel_map(s, 3) >= 0).sum().item()) for s in (1, 2, 4, 8, 16)] == g["pairs"].tolist()
+    m.eval()
+    with torch.no_grad():
+        fused = m(x).F.cpu()
+        m.FUSE_EVAL = False
+        unfused = m(x).F.cpu()
+        m.FUSE_EVAL = True
+    scale = max(1.0, want_eval.abs().max().item())
+    assert (fused - want_eval).abs().max().item() <= TOL * scale, "fused eval path"
+    assert (unfused - want_eval).abs().max().item() <= TOL * scale, "module eval path"
+    m.train()
+    with torch.no_grad():
+        tr = m(x).F.cpu()
+    assert (tr - want_train).abs().max().item() <= TOL * max(1.0, want_train.abs().max().item()), "train-mode BN"
+    # reduced precision slabs stay close to the fp32 result (sanity, not the parity bar)
+    m.eval()
+    with torch.no_grad():
+        xb = ME.SparseTensor(feats.to(torch.bfloat16), torch.from_numpy(coords), device=DEV)
+        ob = m(xb).F.float().cpu()
+    rel = (ob - want_eval).norm() / want_eval.norm()
+    assert rel < 0.05, "bf16 relative error %.4f" % rel
+
+
+def test_linear_heads_and_pooling():
+    """PBNet.py:43-82,274-276: MinkowskiLinear / BN / PReLU / Sigmoid / Softmax on .F, global avg + max pooling."""
+    coords = _scene_coords(45, batch=3)
+    torch.manual_seed(5)
+    feats = torch.randn(len(coords), 32)
+    head = torch.nn.Sequential(ME.MinkowskiLinear(32, 16, bias=False), ME.MinkowskiBatchNorm(16), ME.MinkowskiPReLU(),
+                               ME.MinkowskiLinear(16, 20, bias=True))
+    head.eval()
+    lin0, bn, pr, lin1 = head[0].linear, head[1].bn, head[2].module, head[3].linear
+    with torch.no_grad():
+        want = lin1(pr(bn(lin0(feats))))
+        want_sm = torch.softmax(want, 1)
+    head = head.to(DEV)
+    x = ME.SparseTensor(feats, torch.from_numpy(coords), device=DEV)
+    with torch.no_grad():
+        y = head(x)
+        sm = ME.MinkowskiSoftmax()(y)
+        avg = ME.MinkowskiGlobalAvgPooling()(y)
+        mx = ME.MinkowskiGlobalMaxPooling()(y)
+    assert (y.F.cpu() - want).abs().max().item() <= TOL * max(1.0, want.abs().max().item())
+    assert (sm.F.cpu() - want_sm).abs().max().item() <= TOL
+    b = coords[:, 0]
+    assert (avg.F.cpu() - R.global_pool(want, b, 3, "avg")).abs().max().item() <= TOL * 10
+    assert (mx.F.cpu() - R.global_pool(want, b, 3, "max")).abs().max().item() <= TOL * 10
+    assert ((mx + avg).F.cpu() - (R.global_pool(want, b, 3, "avg") + R.global_pool(want, b, 3, "max"))).abs().max() <= 1e-3
+
+
+def test_full_size_scene_linearity_and_determinism():
+    """BASELINE configs[1] size (145k voxels): convolution is linear in its input, independent of row-tile shape,
+    and bit-reproducible run to run (fixed summation order)."""
+    sc = synth.synth_room(seed=2, pitch=0.0225, room=(4.0, 3.2, 2.6), n_boxes=12)
+    q, _, _ = synth.voxelize_numpy(sc["xyz"], 0.02)
+    coords = np.concatenate([np.zeros((len(q), 1), np.int32), q], 1).astype(np.int32)
+    assert len(coords) > 140000
+    torch.manual_seed(0)
+    conv = ME.MinkowskiConvolution(96, 96, kernel_size=3, dimension=3).to(DEV)
+    a = torch.randn(len(coords), 96, device=DEV)
+    b = torch.randn(len(coords), 96, device=DEV)
+    x = ME.SparseTensor(a, torch.from_numpy(coords), device=DEV)
+    with torch.no_grad():
+        ya = conv(x).F
+        yb = conv(x.replace_feature(b)).F
+        yab = conv(x.replace_feature(a + 2 * b)).F
+        ya2 = conv(x).F
+    assert torch.equal(ya, ya2)
+    assert (yab - (ya + 2 * yb)).abs().max().item() < 1e-3
+    nbr = x.coordinate_manager.kernel_map(1, 3)
+    pairs = int((nbr >= 0).sum().item())
+    assert 6.0 < pairs / len(coords) < 8.5
+    # spot-check 2000 random rows against a direct gather on the GPU tensors
+    rows = torch.randint(0, len(coords), (2000,), device=DEV)
+    nb = nbr[rows].long()
+    ref = torch.zeros(2000, 96, device=DEV, dtype=torch.float64)
+    for k in range(27):
+        valid = nb[:, k] >= 0
+        ref[valid] += a[nb[valid, k]].double() @ conv.kernel[k].double()
+    assert (ya[rows].double() - ref).abs().max().item() < 1e-4
