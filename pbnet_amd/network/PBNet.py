@@ -1,0 +1,333 @@
+"""PBNet model on the MI355X path: same constructor, forward signature, returned dict keys, model_fn /
+model_fn_eval as /root/reference/network/PBNet.py (:18-111 construction, :113-280 forward, :317-347 get_proposal,
+:349-460 model functions), same module / parameter names (state dicts interchange).
+
+What differs is WHERE things run, not what is computed:
+  * the 18 per-class `pbnet_ops.cluster` round trips through host memory (PBNet.py:151-179) become ONE device launch
+    sequence over all (class, batch) segments (`pbnet_ops.cluster_device`); ids are re-based per class on the host so
+    every number matches the per-class calls of the reference;
+  * local-scene construction (PBNet.py:182-234) is split into a tiny host plan over CLUSTERS (kNN of centres with
+    torch.cdist/topk on the CPU exactly as the reference does, size gates, weights) and device gathers over POINTS
+    driven by the ordered member lists the grouping kernel already produced;
+  * get_proposal (PBNet.py:317-347) is a device compaction instead of Python loops.
+One host synchronisation per stage boundary (class counts, cluster table, proposal count), none per class/cluster.
+"""
+import torch
+import torch.nn as nn
+
+from .. import MinkowskiEngine as ME
+from .. import pbnet_ops
+from .Mink import Mink_unet as unet3d
+
+COUNT_MEAN = [-1., -1., 3917., 12056., 2303., 8331., 3948., 3166., 5629., 11719., 1003., 3317., 4912., 10221., 3889.,
+              4136., 2120., 945., 3967., 2589.]                       # PBNet.py:33-34 (softgroup & HAIS)
+LOCAL_VOXEL = 0.02                                                    # PBNet.py:236 (hard-coded)
+MASK_THD = 0.45                                                       # PBNet.py:317
+
+
+def _mlp(cin, mid, cout, sigmoid=False):
+    layers = [ME.MinkowskiLinear(cin, mid, bias=False), ME.MinkowskiBatchNorm(mid), ME.MinkowskiPReLU(),
+              ME.MinkowskiLinear(mid, cout, bias=True)]
+    if sigmoid:
+        layers.append(ME.MinkowskiSigmoid())
+    return nn.Sequential(*layers)
+
+
+class PBNet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.batch_size = cfg.batch_size
+        self.cluster_batch = cfg.batch_size * 1
+        self.sem_num = cfg.sem_num
+        self.voxel_size = cfg.voxel_size
+        self.scale_size = cfg.scale_size
+        self.cluster_epoch = cfg.cluster_epoch
+        self.radius = cfg.radius
+        self.min_pts = cfg.min_pts
+        self.method = getattr(cfg, "method", "PBNet")
+        self.count_mean = torch.tensor(COUNT_MEAN)
+        self.K_max = torch.ones(20, dtype=torch.float32) * 6
+        # three sparse U-Nets (PBNet.py:38-40)
+        self.MEUnet = unet3d(in_channels=6, out_channels=32, arch="MinkUNet34C")
+        self.D_Unet = unet3d(in_channels=34, out_channels=32, arch="MinkUNet14A")
+        self.score_Unet = unet3d(in_channels=32, out_channels=32, arch="MinkUNet34C")
+        # heads (PBNet.py:43-82)
+        self.linear_sem = _mlp(32, 16, self.sem_num)
+        self.linear_offset = _mlp(32, 16, 3)
+        self.linear_binary = _mlp(32, 16, 1, sigmoid=True)
+        self.global_max_pool = ME.MinkowskiGlobalMaxPooling()
+        self.global_avg_pool = ME.MinkowskiGlobalAvgPooling()
+        self.linear_IOU_feat = _mlp(32, 32, 32)
+        self.linear_IOU = _mlp(32, 16, 1, sigmoid=True)
+        self.soft_max = ME.MinkowskiSoftmax()
+        self.weight_initialization()
+        self.fix_module = []
+
+    def weight_initialization(self):
+        for m in self.modules():
+            if isinstance(m, ME.MinkowskiConvolution):
+                ME.utils.kaiming_normal_(m.kernel, mode="fan_out", nonlinearity="relu")
+            if isinstance(m, ME.MinkowskiBatchNorm):
+                nn.init.constant_(m.bn.weight, 1)
+                nn.init.constant_(m.bn.bias, 0)
+
+    # =========================================================================================================
+    def forward(self, feat_voxel, xyz_voxel, xyz_original, v2p_v1, ins_label, epoch, task="train", teacher=None):
+        """teacher: optional dict(sem_score [N,sem_num], offset [N,3]) that REPLACES the two head outputs after they
+        have been computed -- a bench/test hook: randomly initialised heads cannot produce instances."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        stage1 = self.backbone_stage(feat_voxel.to(dev), xyz_voxel.to(dev), v2p_v1.to(dev))
+        if teacher is not None:
+            stage1["sem_pred_score_p"] = teacher["sem_score"].to(dev, stage1["sem_pred_score_p"].dtype)
+            stage1["sem_pred_score_sfp"] = torch.softmax(stage1["sem_pred_score_p"].float(), 1).to(stage1["point_feat_p"].dtype)
+            stage1["offset_pred_p"] = teacher["offset"].to(dev, stage1["offset_pred_p"].dtype)
+            stage1["sem_pred_p"] = stage1["sem_pred_score_p"].max(1)[1]
+        ret = {"sem_pred_p": stage1["sem_pred_p"], "sem_pred_score_p": stage1["sem_pred_score_p"],
+               "offset_pred_p": stage1["offset_pred_p"]}
+        if epoch > self.cluster_epoch:
+            ret.update(self.cluster_stage(stage1, xyz_original.to(dev), None if ins_label is None else ins_label.to(dev),
+                                          task))
+        return ret
+
+    # ---- PBNet.py:117-136 -------------------------------------------------------------------------------------
+    def backbone_stage(self, feat_voxel, xyz_voxel, v2p_v1):
+        inputs_v1 = ME.SparseTensor(feat_voxel, xyz_voxel)
+        point_feat = self.MEUnet(inputs_v1)
+        sem_pred_score = self.linear_sem(point_feat)
+        sem_pred_score_sf = self.soft_max(sem_pred_score)
+        offsets_pred = self.linear_offset(point_feat)
+        v2p = v2p_v1.long()
+        out = {
+            "point_feat_p": point_feat.F[v2p],
+            "sem_pred_score_p": sem_pred_score.F[v2p],
+            "sem_pred_score_sfp": sem_pred_score_sf.F[v2p],
+            "offset_pred_p": offsets_pred.F[v2p],
+            "batch_head_p": xyz_voxel[:, 0][v2p],
+        }
+        out["sem_pred_p"] = out["sem_pred_score_p"].max(1)[1]
+        return out
+
+    # ---- PBNet.py:144-279 -------------------------------------------------------------------------------------
+    def cluster_stage(self, s1, xyz_original, ins_label, task):
+        dev = xyz_original.device
+        xyz_original = xyz_original.float()
+        sem_pred_p, batch_head_p = s1["sem_pred_p"], s1["batch_head_p"].long()
+        point_feat_p, sem_sfp, offset_pred_p = s1["point_feat_p"], s1["sem_pred_score_sfp"], s1["offset_pred_p"]
+        self.cluster_batch = self.batch_size if task == "train" else 3          # PBNet.py:167-170
+        nb = self.cluster_batch
+        n_cls = int(self.sem_num)
+
+        # (a6) per-class selection, all classes at once; host learns the [class, batch] population table
+        table = torch.bincount(sem_pred_p * nb + batch_head_p, minlength=n_cls * nb)[:n_cls * nb].view(n_cls, nb)
+        table_h = table.cpu()                                                     # sync 1
+        assert int(table_h.sum()) == sem_pred_p.shape[0], "batch index outside [0, cluster_batch)"  # PBNet.py:286
+        per_class = table_h.sum(1)
+        classes = [c for c in range(2, n_cls) if not (float(per_class[c]) < float(self.count_mean[c] * 0.05))]
+        if not classes:
+            return self._empty_stage(dev, task)
+        keep = torch.zeros(n_cls, dtype=torch.bool)
+        keep[classes] = True
+        key = torch.where(keep.to(dev)[sem_pred_p], sem_pred_p, torch.full_like(sem_pred_p, n_cls))
+        order = torch.sort(key, stable=True)[1]
+        m = int(per_class[classes].sum())
+        ins_ind = order[:m]                                   # class-major, ascending point index inside a class
+        ins_orig = xyz_original[ins_ind]
+        ins_offseted = ins_orig + offset_pred_p[ins_ind].float()                 # PBNet.py:165 (fp32 add)
+        ins_sem = sem_pred_p[ins_ind].to(torch.int32)
+        seg_len = table[classes].reshape(-1).to(torch.int32)                      # segments = (class, batch) in order
+
+        res = pbnet_ops.cluster_device(ins_offseted, ins_orig, ins_sem, seg_len, self.radius, self.min_pts)
+        n_clt = int(res.n_clusters.item())                                        # sync 2
+        if n_clt < 0:
+            raise RuntimeError("grouping rejected its input (class id outside [2,19])")
+        if n_clt == 0:
+            return self._empty_stage(dev, task)
+        cluster_num = res.cluster_num.cpu().view(len(classes), nb)
+        centers = res.centers[:3 * n_clt].cpu().view(n_clt, 3)
+        member_start = res.member_start[:n_clt + 1].cpu()
+        sizes = (member_start[1:] - member_start[:-1])
+        labels_h = None
+        if task != "test":
+            labels_h = ins_label[ins_ind[res.member_idx[:int(member_start[-1])].long()]].cpu()
+
+        # (a17) host plan over clusters: which clusters make up each local scene, and with which weight
+        ent_cluster, ent_weight, scene_len, scene_gt = [], [], [], []
+        g = 0                                                   # running global cluster id (class-major, batch, seed)
+        for ci, cls in enumerate(classes):
+            for b in range(nb):
+                c_b = int(cluster_num[ci, b])
+                if c_b == 0:
+                    continue
+                para_k = min(c_b - 1, int(self.K_max[cls]))
+                if para_k > 0:
+                    peak_v = [0.5 * ((para_k + 1) - p_i) / (para_k + 1) for p_i in range(para_k + 1)]
+                    ctr = centers[g:g + c_b]
+                    knn_idx = torch.cdist(ctr, ctr).topk(k=c_b, dim=1, largest=False)[1]
+                for c_i in range(c_b):
+                    gid = g + c_i
+                    gt = None
+                    if task != "test":
+                        gt = int(torch.mode(labels_h[int(member_start[gid]):int(member_start[gid + 1])])[0])
+                        if gt == -100:
+                            continue
+                    ents, wts = [gid], [1.0]
+                    if float(sizes[gid]) > float(self.count_mean[cls] * 0.2) and para_k > 0:
+                        for k_i in range(para_k):
+                            ents.append(g + int(knn_idx[c_i, k_i + 1]))
+                            wts.append(peak_v[k_i])
+                    ent_cluster += ents
+                    ent_weight += wts
+                    scene_len.append(len(ents))
+                    scene_gt.append(gt)
+                g += c_b
+        if not scene_len:
+            return self._empty_stage(dev, task)
+
+        # device gathers over points: rows of every local scene, in the reference's order
+        ent_cluster_t = torch.tensor(ent_cluster, dtype=torch.long)
+        ent_rows = sizes[ent_cluster_t]
+        ent_scene = torch.repeat_interleave(torch.arange(len(scene_len)), torch.tensor(scene_len))
+        d = lambda t: t.to(dev)
+        row_ent = torch.repeat_interleave(torch.arange(len(ent_cluster), device=dev), d(ent_rows))
+        ent_first = d(torch.cumsum(ent_rows, 0) - ent_rows)
+        pos_in_ent = torch.arange(row_ent.shape[0], device=dev) - ent_first[row_ent]
+        member_pos = d(member_start[:-1][ent_cluster_t])[row_ent] + pos_in_ent
+        local_idx = res.member_idx[member_pos].long()                            # index into the grouped array
+        point_idx = ins_ind[local_idx]                                           # index into the scene's points
+        row_scene = d(ent_scene)[row_ent]
+        row_weight = d(torch.tensor(ent_weight, dtype=torch.float32))[row_ent]
+        row_sem_sf = sem_sfp[point_idx, sem_pred_p[point_idx]]                    # PBNet.py:162-163: own-class score
+        feat = torch.cat([point_feat_p[point_idx], row_sem_sf.view(-1, 1).to(point_feat_p.dtype),
+                          row_weight.view(-1, 1).to(point_feat_p.dtype)], 1)     # [R, 34]  PBNet.py:194,230
+        out = {}
+
+        # (a18) mask branch
+        coords = torch.cat([row_scene.view(-1, 1).to(torch.int32),
+                            torch.floor(xyz_original[point_idx] / LOCAL_VOXEL).to(torch.int32)], 1)
+        inputs_v2 = ME.SparseTensor(feat, coords)
+        mask_score = self.linear_binary(self.D_Unet(inputs_v2)).F[inputs_v2.inverse_mapping]   # [R, 1]
+        if task != "test":
+            gt_rows = d(torch.tensor(scene_gt, dtype=torch.long))[row_scene]
+            lab = ins_label[point_idx]
+            gt_mask = (lab == gt_rows).long()
+            gt_mask[lab == -100] = -1
+            out["mask_scores"] = (mask_score, gt_mask.detach())
+        out["proposals"] = self.get_proposal(row_scene, point_idx, mask_score)
+
+        # (a20) score branch
+        proposals_idx, proposals_offset, _, _ = out["proposals"]
+        if proposals_offset.shape[0] > 1:
+            pidx = proposals_idx[:, 1]
+            c3 = torch.floor(xyz_original[pidx] * self.scale_size / self.voxel_size).to(torch.int32)
+            coords3 = torch.cat([proposals_idx[:, 0:1].to(torch.int32), c3], 1)
+            inputs_v3 = ME.SparseTensor(point_feat_p[pidx], coords3)
+            iou_feat = self.linear_IOU_feat(self.score_Unet(inputs_v3))
+            global_feat = self.global_max_pool(iou_feat) + self.global_avg_pool(iou_feat)
+            out["clt_scores"] = self.linear_IOU(global_feat).F.view(-1)
+        else:
+            out["clt_scores"] = torch.zeros(0, dtype=torch.float32, device=dev)
+        return out
+
+    def _empty_stage(self, dev, task):
+        z = torch.zeros(0, dtype=torch.int64, device=dev)
+        out = {"proposals": (torch.zeros(0, 2, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev),
+                             z, torch.zeros(0, device=dev)),
+               "clt_scores": torch.zeros(0, device=dev)}
+        if task != "test":
+            out["mask_scores"] = (torch.zeros(0, 1, device=dev), z)
+        return out
+
+    # ---- PBNet.py:317-347 as one device compaction ----------------------------------------------------------------
+    def get_proposal(self, row_scene, point_idx, mask_score, mask_score_thd=MASK_THD):
+        assert row_scene.shape[0] == mask_score.shape[0]
+        valid = torch.nonzero(mask_score.view(-1).float() > mask_score_thd).view(-1)
+        scene = row_scene[valid]
+        proposals_ms = mask_score[valid].view(-1)
+        cluster_id_v, dense, cluster_len = torch.unique(scene, return_inverse=True, return_counts=True)
+        proposals_offset = torch.zeros(cluster_len.shape[0] + 1, dtype=torch.int64, device=scene.device)
+        proposals_offset[1:] = torch.cumsum(cluster_len, 0)
+        # "remove null proposals" (PBNet.py:342-345) == dense renumbering of the surviving local scenes
+        proposals_idx = torch.stack([dense.view(-1), point_idx[valid]], 1).to(torch.int64)
+        return proposals_idx.detach(), proposals_offset.detach(), cluster_id_v.detach(), proposals_ms
+
+
+def model_fn(batch, model, epoch, cfg, task="train"):
+    """PBNet.py:349-444: forward + losses.  Losses are plain torch on the device (outside the kernel scope)."""
+    from .. import pbnet_ops as ops
+    xyz_original = batch["xyz_original"].cuda()
+    ins_label = batch["ins"].cuda()
+    ret = model(batch["feat_voxel"], batch["xyz_voxel"], xyz_original, batch["v2p_index"], ins_label, epoch, task)
+    sem_label = batch["sem"].cuda()
+    instance_info = batch["inst_info"].cuda()
+    instance_pointnum = batch["instance_pointnum"].cuda()
+    sem_pred_score_p, offset_pred_p, sem_pred_p = ret["sem_pred_score_p"].float(), ret["offset_pred_p"].float(), ret["sem_pred_p"]
+
+    semantic_loss = nn.CrossEntropyLoss(ignore_index=-100)(sem_pred_score_p, sem_label)
+    gt_offsets = instance_info[:, 0:3] - xyz_original
+    pt_dist = torch.sum(torch.abs(offset_pred_p - gt_offsets), dim=-1)
+    valid = (ins_label != -100).float()
+    offset_norm_loss = torch.sum(pt_dist * valid) / (torch.sum(valid) + 1e-6)
+    gt_dir = gt_offsets / (torch.norm(gt_offsets, p=2, dim=1).unsqueeze(-1) + 1e-8)
+    pt_dir = offset_pred_p / (torch.norm(offset_pred_p, p=2, dim=1).unsqueeze(-1) + 1e-8)
+    offset_dir_loss = torch.sum(-(gt_dir * pt_dir).sum(-1) * valid) / (torch.sum(valid) + 1e-6)
+    loss = semantic_loss + offset_norm_loss + offset_dir_loss
+
+    if epoch > cfg.cluster_epoch:
+        pred_mask, gt_mask = ret["mask_scores"]
+        pred_mask = pred_mask.float()
+        weight = (gt_mask != -1).float()
+        target = gt_mask.float().clone()
+        target[gt_mask == -1] = 0.5
+        mask_loss = nn.BCELoss(reduction="none", weight=weight)(pred_mask.view(-1), target).mean()
+        loss = loss + mask_loss
+        sel = gt_mask != -1
+        loss = loss + diceLoss(pred_mask.view(-1)[sel], gt_mask[sel].float())
+        proposals_idx, proposals_offset, _, _ = ret["proposals"]
+        ious = ops.get_iou(proposals_idx[:, 1].contiguous().cuda(), proposals_offset.cuda(), ins_label, instance_pointnum)
+        gt_ious, _ = ious.max(1)
+        gt_scores = get_segmented_scores(gt_ious, cfg.fg_thresh, cfg.bg_thresh)
+        score_loss = nn.BCELoss()(ret["clt_scores"].float().view(-1), gt_scores).mean()
+        loss = loss + score_loss
+
+    with torch.no_grad():
+        pred = {"sem": sem_pred_p, "offseted_xyz": xyz_original + offset_pred_p}
+        visual_dict = {"loss": loss.item(), "semantic_loss": semantic_loss.item(),
+                       "offset_norm_loss": offset_norm_loss.item(), "offset_dir_loss": offset_dir_loss.item()}
+        meter_dict = {k: (v, valid.sum()) for k, v in visual_dict.items()}
+        if epoch > cfg.cluster_epoch:
+            visual_dict["mask_loss"] = mask_loss.item()
+            meter_dict["mask_loss"] = (mask_loss.item(), weight.sum())
+            pred["mask_scores"] = ret["mask_scores"]
+            pred["proposals"] = ret["proposals"]
+            pred["clt_scores"] = ret["clt_scores"]
+    return loss, pred, visual_dict, meter_dict
+
+
+def model_fn_eval(batch, model, epoch, cfg, task="test", teacher=None):
+    """PBNet.py:446-460."""
+    ret = model(batch["feat_voxel"], batch["xyz_voxel"], batch["xyz_original"], batch["v2p_index"], None, epoch, task,
+                teacher=teacher)
+    pred = {"sem": ret["sem_pred_p"]}
+    if epoch > cfg.cluster_epoch:
+        pred["proposals"] = ret["proposals"]
+        pred["clt_scores"] = ret["clt_scores"]
+    return pred
+
+
+def get_segmented_scores(scores, fg_thresh=1.0, bg_thresh=0.0):
+    """/root/reference/tools/mIOU.py:34-49 (linear ramp between the two thresholds)."""
+    fg_mask = scores > fg_thresh
+    bg_mask = scores < bg_thresh
+    interval_mask = (fg_mask == 0) & (bg_mask == 0)
+    out = (fg_mask > 0).float()
+    k = 1 / (fg_thresh - bg_thresh)
+    b = bg_thresh / (bg_thresh - fg_thresh)
+    out[interval_mask] = scores[interval_mask] * k + b
+    return out
+
+
+def diceLoss(mask_pred, mask_gt, ep=1e-8):
+    """PBNet.py:463-468."""
+    inter = 2 * (mask_gt * mask_pred).sum() + 1
+    union = (mask_gt ** 2.0).sum() + (mask_pred ** 2.0).sum() + 1 + ep
+    return 1 - inter / union
