@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config, on N MI355X of one node.
+
+metric  : scenes/s of PBNet.forward + binarize + cluster (backbone, heads, grouping, mask U-Net, proposals, score
+          U-Net), inputs already voxelised and resident in HBM when the timed region starts.
+workload: configs[1] -- one synthetic ScanNet-sized scene (seed 2: 161 517 points, 146 038 voxels at 2 cm),
+          MinkUNet34C backbone, bf16 feature slabs with fp32 accumulation, random-init weights (torch.manual_seed(22),
+          the reference's init rule).  Randomly initialised heads cannot produce instances, so the semantic / offset
+          head outputs are overwritten by teacher-forced values AFTER they have been computed; every
+          stage of the path therefore runs inside the timed region on realistic, data-dependent sizes.
+step    : one PBNet.forward over one scene per rank.  N > 1: every rank owns a different scene (seed 2 + rank), no
+          data-path collective (scenes are independent at inference) -> weak scaling; the process group only carries
+          the barrier and the max-over-ranks of the elapsed time.
+
+Also on the JSON line:
+  roofline     -- the dominant kernel family (k_spconv, csrc/spconv.hip): algorithmic bytes of every launch (SURVEY.md
+                  8d: (V_in*C_in + V_out*C_out)*b + K*C_in*C_out*b + 8*P) divided by that launch's duration, measured
+                  with HIP events on the launching stream in an instrumented pass over the same steps.
+  cpu_baseline -- the CPU oracle (oracle/, a restatement: the reference's own CPU path cannot be installed) timed on
+                  the host cores of rank 0 at N=1 on one full scene of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def build_workload(rank, copies, dtype, device):
+    from pbnet_amd import synth
+    from pbnet_amd.config import get_config
+    from pbnet_amd.network.PBNet import PBNet
+    cfg = get_config(test=True)
+    torch.manual_seed(22)  # /root/reference/config/config.py:15
+    model = PBNet(cfg).to(device).eval()
+    batch, teacher, info = synth.make_val_batch(seed=2 + rank, copies=copies)
+    b = {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
+    b["feat_voxel"] = b["feat_voxel"].to(dtype)
+    t = {k: torch.from_numpy(v).to(device) for k, v in teacher.items()}
+    return cfg, model, b, t, info, (batch, teacher)
+
+
+def one_step(model, b, t):
+    with torch.no_grad():
+        return model(b["feat_voxel"], b["xyz_voxel"], b["xyz_original"], b["v2p_index"], None, 1, "test", teacher=t)
+
+
+class ConvProbe(object):
+    """Instrumented pass: HIP events (torch.cuda.Event on the launching stream) around every k_spconv launch plus the
+    launch's algorithmic bytes / flops."""
+
+    def __init__(self):
+        self.records = []
+        self.pair_cache = {}
+
+    def install(self):
+        from pbnet_amd.MinkowskiEngine import conv as C
+        from pbnet_amd.network import mink_unet as U
+        self._orig = C.spconv_forward
+        probe = self
+
+        def wrapped(feats, nbr, n_out, packed, **kw):
+            w, vpo, n_steps, cout_p = packed
+            esz = feats.element_size()
+            k = 1 if nbr is None else int(nbr.shape[1])
+            cin = int(feats.shape[1])
+            if nbr is None:
+                pairs, rule_bytes = int(n_out), 0
+            else:
+                key = nbr.data_ptr()
+                if key not in probe.pair_cache:
+                    probe.pair_cache[key] = int((nbr >= 0).sum().item())
+                pairs = probe.pair_cache[key]
+                rule_bytes = 8 * pairs
+            cout = cout_p
+            n_in = int(feats.shape[0])
+            nbytes = (n_in * cin + int(n_out) * cout) * esz + k * cin * cout * esz + rule_bytes
+            if kw.get("residual") is not None:
+                nbytes += int(n_out) * cout * esz
+            flops = 2 * pairs * cin * cout
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = probe._orig(feats, nbr, n_out, packed, **kw)
+            e1.record()
+            probe.records.append((e0, e1, nbytes, flops))
+            return out
+
+        C.spconv_forward = wrapped
+        U.spconv_forward = wrapped
+        self._mods = (C, U)
+
+    def remove(self):
+        for m in self._mods:
+            m.spconv_forward = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        t_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
+        nbytes = sum(r[2] for r in self.records)
+        flops = sum(r[3] for r in self.records)
+        n = len(self.records)
+        return n, t_ms, nbytes, flops
+
+
+def cpu_baseline(cfg, model, raw):
+    """Oracle (kind "port") on the host cores: one full scene of the same workload."""
+    from oracle import pbnet_ref
+    batch, teacher = raw
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    tt = {k: torch.from_numpy(v) for k, v in teacher.items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    s1 = pbnet_ref.backbone_stage(sd, tb["feat_voxel"], tb["xyz_voxel"], tb["v2p_index"])
+    s1["sem_pred_score_p"] = tt["sem_score"]
+    s1["sem_pred_score_sfp"] = torch.softmax(tt["sem_score"], 1)
+    s1["offset_pred_p"] = tt["offset"]
+    s1["sem_pred_p"] = tt["sem_score"].max(1)[1]
+    pbnet_ref.cluster_stage(sd, cfg, s1, tb["xyz_original"], None, "test")
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": "1 full scene of the same workload (fp32 torch gather-mm-index_add backbone on all host cores + "
+                      "single-thread C grouping), %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--copies", type=int, default=1, help="rotated copies per scene (reference eval uses 3: TTA)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    cfg, model, b, t, info, raw = build_workload(rank, args.copies, dtype, device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ret = None
+    for _ in range(args.warmup):
+        ret = one_step(model, b, t)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ret = one_step(model, b, t)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    n_prop = int(ret["proposals"][1].shape[0] - 1)
+
+    roof = None
+    cpu = None
+    if rank == 0:
+        probe = ConvProbe()
+        probe.install()
+        for _ in range(max(2, min(args.steps, 5))):
+            one_step(model, b, t)
+        n_launch, t_ms, nbytes, flops = probe.summary()
+        probe.remove()
+        achieved = nbytes / (t_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv",
+                "launches_per_step": n_launch // max(2, min(args.steps, 5)),
+                "avg_launch_us": round(t_ms * 1e3 / n_launch, 2),
+                "algorithmic_bytes_per_launch": int(nbytes / n_launch),
+                "achieved_tflops": round(flops / (t_ms * 1e-3) / 1e12, 2)}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, model, raw)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        line = {
+            "metric": "scenes/sec fwd+cluster (ScanNet ~150k pts/scene)",
+            "value": round(world * args.steps / elapsed, 3),
+            "unit": "scenes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic room scene (pbnet_amd/synth.py), random-init weights (seed 22), teacher-forced "
+                    "semantic/offset head outputs",
+            "config": {"workload": "configs[1]: 1 scene, %d pts, %d voxels @2cm, %d rotated cop%s, full "
+                                   "PBNet.forward (MinkUNet34C + grouping + MinkUNet14A mask + MinkUNet34C score)"
+                                   % (info["n_points"] // args.copies, info["n_voxels"] // args.copies, args.copies,
+                                      "y" if args.copies == 1 else "ies"),
+                       "points_per_step": info["n_points"], "voxels_per_step": info["n_voxels"],
+                       "proposals_per_step": n_prop, "parallelism": "1 scene per GPU, no data-path collective"},
+            "roofline": roof,
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -94,3 +94,44 @@ def voxelize_numpy(xyz, voxel_size):
     rank = np.empty_like(order)
     rank[order] = np.arange(len(order))
     return q[first[order]], first[order], rank[inverse.reshape(-1)]
+
+
+TTA_ANGLES = (63.0, 183.0, 303.0)   # /root/reference/datasets/scannetv2/dataset_preprocess.py:91
+
+
+def make_val_batch(seed=2, copies=1, room=(4.0, 3.2, 2.6), n_boxes=12, pitch=0.0225, classes=None, voxel=0.02):
+    """A val-style batch dict as dataset_preprocess.valMerge builds it (:308-385): `copies` rotated copies of one
+    scene (:324,344), each voxelised at `voxel` m, plus teacher-forced head outputs for the grouping stage.
+
+    Returns (batch, teacher, info): batch has xyz_voxel i32[V,4], feat_voxel f32[V,6], xyz_original f32[N,3],
+    v2p_index i64[N], ins i64[N]; teacher has sem_score f32[N,20] and offset f32[N,3]; numpy arrays throughout."""
+    sc = synth_room(seed=seed, pitch=pitch, room=room, n_boxes=n_boxes)
+    if classes is not None:
+        box = sc["ins"] >= 0
+        sc["sem"][box] = np.asarray(classes)[sc["ins"][box] % len(classes)]
+    sem_pred, offset = teacher_forced_heads(sc, seed=seed)
+    xyz_l, vox_l, feat_l, v2p_l, off_l, ins_l = [], [], [], [], [], []
+    nv = 0
+    for b in range(copies):
+        th = np.deg2rad(TTA_ANGLES[b % 3])
+        rot = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+        xyz = sc["xyz"].astype(np.float64) @ rot.T
+        xyz = (xyz - xyz.min(0)).astype(np.float32)
+        q, first, inv = voxelize_numpy(xyz, voxel)
+        feats = np.concatenate([sc["rgb"], (sc["normal"].astype(np.float64) @ rot.T).astype(np.float32)], 1)
+        vox_l.append(np.concatenate([np.full((len(q), 1), b, np.int32), q], 1))
+        feat_l.append(feats[first].astype(np.float32))
+        v2p_l.append(inv + nv)
+        nv += len(q)
+        xyz_l.append(xyz)
+        off_l.append((offset.astype(np.float64) @ rot.T).astype(np.float32))
+        ins_l.append(np.where(sc["ins"] >= 0, sc["ins"] + b * n_boxes, -100))
+    sem = np.tile(sem_pred, copies)
+    score = np.full((len(sem), 20), -5.0, np.float32)
+    score[np.arange(len(sem)), sem] = 5.0
+    batch = dict(xyz_voxel=np.concatenate(vox_l).astype(np.int32), feat_voxel=np.concatenate(feat_l),
+                 xyz_original=np.concatenate(xyz_l), v2p_index=np.concatenate(v2p_l).astype(np.int64),
+                 ins=np.concatenate(ins_l).astype(np.int64))
+    teacher = dict(sem_score=score, offset=np.concatenate(off_l))
+    info = dict(n_points=int(len(sem)), n_voxels=int(nv), copies=copies, seed=seed)
+    return batch, teacher, info

@@ -16,40 +16,12 @@ DEV = "cuda:0"
 TOL = 1e-4
 
 
-def make_batch(seed=1, copies=3, room=(1.6, 1.3, 1.2), n_boxes=6, pitch=0.03, classes=(17, 10)):
-    """A val-style batch: `copies` rotated copies of one scene (dataset_preprocess.py:324,344), voxelised at 2 cm."""
-    sc = synth.synth_room(seed=seed, pitch=pitch, room=room, n_boxes=n_boxes)
-    sem_gt = sc["sem"].copy()
-    box = sc["ins"] >= 0
-    sem_gt[box] = np.asarray(classes)[sc["ins"][box] % len(classes)]
-    sc["sem"] = sem_gt
-    sem_pred, offset = synth.teacher_forced_heads(sc, seed=seed)
-    xyz_l, vox_l, feat_l, v2p_l, sem_l, off_l, ins_l = [], [], [], [], [], [], []
-    nv = 0
-    for b in range(copies):
-        th = np.deg2rad([63.0, 183.0, 303.0][b % 3])
-        Rm = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
-        xyz = (sc["xyz"].astype(np.float64) @ Rm.T)
-        xyz = (xyz - xyz.min(0)).astype(np.float32)
-        q, first, inv = synth.voxelize_numpy(xyz, 0.02)
-        feats = np.concatenate([sc["rgb"], sc["normal"] @ Rm.T.astype(np.float32)], 1).astype(np.float32)
-        vox_l.append(np.concatenate([np.full((len(q), 1), b, np.int32), q], 1))
-        feat_l.append(feats[first])
-        v2p_l.append(inv + nv)
-        nv += len(q)
-        xyz_l.append(xyz)
-        sem_l.append(sem_pred)
-        off_l.append((offset.astype(np.float64) @ Rm.T).astype(np.float32))
-        ins_l.append(np.where(sc["ins"] >= 0, sc["ins"] + b * n_boxes, -100))
+def make_batch(seed=1, copies=3):
+    """3 rotated copies of a 6-box scene whose boxes alternate between two small-threshold classes."""
+    batch, teacher, _ = synth.make_val_batch(seed=seed, copies=copies, room=(1.6, 1.3, 1.2), n_boxes=6, pitch=0.03,
+                                             classes=(17, 10))
     t = torch.from_numpy
-    batch = dict(xyz_voxel=t(np.concatenate(vox_l).astype(np.int32)), feat_voxel=t(np.concatenate(feat_l)),
-                 xyz_original=t(np.concatenate(xyz_l)), v2p_index=t(np.concatenate(v2p_l).astype(np.int64)),
-                 ins=t(np.concatenate(ins_l).astype(np.int64)))
-    sem = np.concatenate(sem_l)
-    score = np.full((len(sem), 20), -5.0, np.float32)
-    score[np.arange(len(sem)), sem] = 5.0
-    teacher = dict(sem_score=t(score), offset=t(np.concatenate(off_l)))
-    return batch, teacher
+    return {k: t(v) for k, v in batch.items()}, {k: t(v) for k, v in teacher.items()}
 
 
 @pytest.fixture(scope="module")
