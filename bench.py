@@ -118,7 +118,8 @@ def cpu_baseline(cfg, model, raw):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     tb = {k: torch.from_numpy(v) for k, v in batch.items()}
     tt = {k: torch.from_numpy(v) for k, v in teacher.items()}
-    cores = os.cpu_count() or 1
+    from pbnet_amd.hostinfo import usable_cores
+    cores = usable_cores()
     torch.set_num_threads(cores)
     t0 = time.perf_counter()
     s1 = pbnet_ref.backbone_stage(sd, tb["feat_voxel"], tb["xyz_voxel"], tb["v2p_index"])

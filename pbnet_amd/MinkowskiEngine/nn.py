@@ -31,7 +31,10 @@ class _Elementwise(nn.Module):
         self.module = self.MODULE(*args, **kwargs)
 
     def forward(self, x):
-        return x.replace_feature(self.module(x.F))
+        f = x.F
+        if f.dtype != torch.float32 and any(True for _ in self.module.parameters()):
+            return x.replace_feature(self.module(f.float()).to(f.dtype))  # fp32 parameters (PReLU slope)
+        return x.replace_feature(self.module(f))
 
 
 class MinkowskiReLU(_Elementwise):

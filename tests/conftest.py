@@ -10,6 +10,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 
 def pytest_configure(config):
+    import torch
+    from pbnet_amd.hostinfo import usable_cores
+    torch.set_num_threads(usable_cores())  # the GPU boxes cap the container far below os.cpu_count()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
