@@ -142,12 +142,17 @@ int pbn_up_table(const int32_t* parent_row, const int32_t* child_k, const int32_
  *  scale/shift [cout_padded] f32 or NULL (folded eval-mode BatchNorm / bias)
  *  residual  [*, ld_res] T or NULL;  relu != 0 applies max(.,0);  out_feat [*, ld_out] T, cout_padded columns written
  *  dtype     PBN_F32 (v_mfma_f32_16x16x4_f32, exact fp32: the parity configuration), PBN_BF16, PBN_F16
- *  rows_per_wave 16, 32 or 0 (auto).  fp32 accumulation, fixed summation order: results are deterministic.
+ *  rows_per_wave 16, 32 or 0 (auto).
+ *  workspace     optional scratch (16-byte aligned) for split-K launches: when the row count is too small to fill the
+ *                256 CUs the reduction axis is cut into slices whose fp32 partial sums go through this buffer and are
+ *                combined in a fixed order by a second kernel; NULL / too small => single-pass launch.
+ *  fp32 accumulation, fixed summation order: results are deterministic (bit-identical run to run).
  */
 int pbn_spconv_forward(const void* in_feat, int ld_in, const int32_t* nbr, int n_offsets, const int32_t* row_perm,
                        const int32_t* n_out_dev, int n_out, const void* w_packed, int vecs_per_offset, int n_steps,
                        int cout_padded, const float* scale, const float* shift, const void* residual, int ld_res,
-                       int relu, void* out_feat, int ld_out, int dtype, int rows_per_wave, pbn_stream_t stream);
+                       int relu, void* out_feat, int ld_out, int dtype, int rows_per_wave, void* workspace,
+                       size_t workspace_bytes, pbn_stream_t stream);
 
 /* out[i, :] = in[idx[i], :] on 16-byte multiples (voxel -> point gathers, network/PBNet.py:130-134,250). */
 int pbn_gather_rows(const void* in, int ld_in_bytes, const int64_t* idx, int n, int row_bytes, void* out,

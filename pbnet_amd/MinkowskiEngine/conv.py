@@ -67,6 +67,19 @@ class _PackCache(object):
         return hit[1]
 
 
+_WS = {}
+SPLITK_WORKSPACE_BYTES = 256 << 20
+
+
+def _workspace(device):
+    """Per-device scratch for split-K launches (fp32 partial slabs), allocated once."""
+    ws = _WS.get(device)
+    if ws is None:
+        ws = torch.empty(SPLITK_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        _WS[device] = ws
+    return ws
+
+
 def spconv_forward(feats, nbr, n_out, packed, scale=None, shift=None, residual=None, relu=False, out=None,
                    row_perm=None, rows_per_wave=0):
     """Launch pbn_spconv_forward.  feats [n_in, C] (row stride = feats.stride(0)), nbr int32 [n_out, K] or None.
@@ -88,12 +101,14 @@ def spconv_forward(feats, nbr, n_out, packed, scale=None, shift=None, residual=N
     assert out.stride(1) == 1 and out.shape[1] >= cout_p and out.dtype == dtype
     if residual is not None:
         assert residual.stride(1) == 1 and residual.dtype == dtype and residual.shape[1] >= cout_p
+    ws = _workspace(feats.device)
     rc = N.lib().pbn_spconv_forward(
         N.c_vp(feats.data_ptr()), feats.stride(0), None if nbr is None else N.c_vp(nbr.data_ptr()), k,
         None if row_perm is None else N.c_vp(row_perm.data_ptr()), None, int(n_out), N.c_vp(w.data_ptr()), vpo, n_steps,
         cout_p, None if scale is None else N.c_vp(scale.data_ptr()), None if shift is None else N.c_vp(shift.data_ptr()),
         None if residual is None else N.c_vp(residual.data_ptr()), 0 if residual is None else residual.stride(0),
-        int(bool(relu)), N.c_vp(out.data_ptr()), out.stride(0), _DT[dtype], int(rows_per_wave), N.current_stream())
+        int(bool(relu)), N.c_vp(out.data_ptr()), out.stride(0), _DT[dtype], int(rows_per_wave),
+        N.c_vp(ws.data_ptr()), ws.numel(), N.current_stream())
     N.check(rc, "pbn_spconv_forward")
     return out
 

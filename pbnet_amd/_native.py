@@ -37,7 +37,7 @@ SIGNATURES = {
     "pbn_kernel_map": (c_int, [c_i32p, c_i32p, c_int, c_i32p, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_up_table": (c_int, [c_i32p, c_i32p, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_spconv_forward": (c_int, [c_vp, c_int, c_i32p, c_int, c_i32p, c_i32p, c_int, c_vp, c_int, c_int, c_int,
-                                   c_f32p, c_f32p, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp]),
+                                   c_f32p, c_f32p, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "pbn_gather_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
 }
 

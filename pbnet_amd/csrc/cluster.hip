@@ -158,7 +158,15 @@ __global__ __launch_bounds__(TPB) void k_count(const float4* __restrict__ spt, c
     const float4 me = spt[p];
     int cnt = 0;
     for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount, [&](int beg, int end) {
-        for (int j = beg; j < end; ++j) {
+        int j = beg;
+        for (; j + 4 <= end; j += 4) {  // 4 independent loads in flight
+            const float4 q0 = spt[j], q1 = spt[j + 1], q2 = spt[j + 2], q3 = spt[j + 3];
+            cnt += (sqdist(me.x, me.y, me.z, q0.x, q0.y, q0.z) <= r2) ? 1 : 0;
+            cnt += (sqdist(me.x, me.y, me.z, q1.x, q1.y, q1.z) <= r2) ? 1 : 0;
+            cnt += (sqdist(me.x, me.y, me.z, q2.x, q2.y, q2.z) <= r2) ? 1 : 0;
+            cnt += (sqdist(me.x, me.y, me.z, q3.x, q3.y, q3.z) <= r2) ? 1 : 0;
+        }
+        for (; j < end; ++j) {
             const float4 q = spt[j];
             cnt += (sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) ? 1 : 0;
         }
@@ -208,7 +216,7 @@ __device__ __forceinline__ int uf_union(int* __restrict__ parent, int a, int b) 
 __global__ __launch_bounds__(TPB) void k_union(const float4* __restrict__ spt, const int* __restrict__ sseg, int n,
                                               float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
                                               unsigned hmask, const int* __restrict__ hstart,
-                                              const int* __restrict__ hcount, int* __restrict__ parent) {
+                                              const int* __restrict__ hcount, int* parent) {
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= n) return;
     const float4 me = spt[p];
@@ -222,7 +230,9 @@ __global__ __launch_bounds__(TPB) void k_union(const float4* __restrict__ spt, c
             const int wj = __float_as_int(q.w);
             const int jj = wj & 0x7fffffff;
             if (wj < 0 && jj < i && sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) {
-                if (uf_load(&parent[jj]) != ri) ri = uf_union(parent, ri, jj);
+                // Shortcut on a plain (L1-cached, possibly stale) read: a stale parent is still a former ancestor,
+                // i.e. a member of the same set, so equality proves "already merged"; inequality only costs a union.
+                if (parent[jj] != ri) ri = uf_union(parent, ri, jj);
             }
         }
     });
@@ -323,24 +333,39 @@ __global__ __launch_bounds__(TPB) void k_relabel(const int* __restrict__ lab, co
                                                 int n, int* __restrict__ lab2, int* __restrict__ cluster_id,
                                                 int* __restrict__ clt_sem, int* __restrict__ clt_seg,
                                                 int* __restrict__ last_assigned, int* __restrict__ fsize,
-                                                int* __restrict__ noise_flag, float4* __restrict__ cand) {
-    const int i = blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
+                                                int* __restrict__ noise_flag, float4* __restrict__ cand,
+                                                const int* __restrict__ size) {
+    int i = blockIdx.x * TPB + threadIdx.x;
+    const bool live = i < n;
+    if (!live) i = n - 1;  // keep whole waves alive for the shuffles below; duplicates of the last point are harmless
     const int s = lab[i];
     const int id = (s >= 0 && keep[s]) ? newid[s] : -1;
-    lab2[i] = id;
-    cluster_id[i] = id;
-    noise_flag[i] = id < 0;
+    if (live) {
+        lab2[i] = id;
+        cluster_id[i] = id;
+        noise_flag[i] = id < 0;
+    }
     if (keep[i]) {
         clt_sem[newid[i]] = sem[i];
         clt_seg[newid[i]] = seg_of_pt[i];
+        fsize[newid[i]] = size[i];  // HPs + border LPs; unassigned points are added by k_noise_nn
     }
-    if (id >= 0) {
-        atomicMax(&last_assigned[seg_of_pt[i]], i);
-        atomicAdd(&fsize[id], 1);
+    {   // highest assigned index per segment: one atomic per wave when the wave sits in one segment (the usual case)
+        const int seg = seg_of_pt[i];
+        const int cand_i = (id >= 0) ? i : -1;
+        const int seg0 = __shfl(seg, 0, 64);
+        if (__all(seg == seg0)) {
+            int m = cand_i;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+            if (lane_id() == 0 && m >= 0) atomicMax(&last_assigned[seg0], m);
+        } else if (cand_i >= 0) {
+            atomicMax(&last_assigned[seg], cand_i);
+        }
     }
-    cand[i] = make_float4(org_xyz[3 * i + 0], org_xyz[3 * i + 1], org_xyz[3 * i + 2],
-                          __int_as_float(id >= 0 ? sem[i] : -1));
+    if (live)
+        cand[i] = make_float4(org_xyz[3 * i + 0], org_xyz[3 * i + 1], org_xyz[3 * i + 2],
+                              __int_as_float(id >= 0 ? ((seg_of_pt[i] << 8) | sem[i]) : -1));
 }
 
 __global__ void k_cluster_num(const int* __restrict__ newid, const int* __restrict__ seg_off, int n_seg, int n,
@@ -362,72 +387,119 @@ __global__ __launch_bounds__(TPB) void k_compact_noise(const int* __restrict__ n
 }
 
 // a15: exact nearest assigned point of the same class, ORIGINAL coordinates, ties -> highest index
-// (binary_cuda_functions.cu:258-302).  Thread per unassigned point; candidates streamed in ascending index so the
-// `<=` update reproduces the reference scan order.
+// (binary_cuda_functions.cu:258-302).  Thread per unassigned point (compacted list, ascending index).  A workgroup's
+// points span a contiguous run of segments; that run is streamed once through LDS in ascending index, so the `<=`
+// update reproduces the reference's scan order while every candidate costs one broadcast ds_read instead of a
+// dependent global load.  cand.w = (segment << 8 | class) for assigned points, -1 otherwise.
 __global__ __launch_bounds__(TPB) void k_noise_nn(const int* __restrict__ noise_list, const int* __restrict__ n_noise,
                                                  const float4* __restrict__ cand, const int* __restrict__ sem,
                                                  const int* __restrict__ seg_of_pt, const int* __restrict__ seg_off,
                                                  const int* __restrict__ lab2, const int* __restrict__ last_assigned,
                                                  int* __restrict__ cluster_id, int* __restrict__ fsize) {
-    const int t = blockIdx.x * TPB + threadIdx.x;
-    if (t >= *n_noise) return;
-    const int i = noise_list[t];
-    const int seg = seg_of_pt[i];
-    const int beg = seg_off[seg], end = seg_off[seg + 1];
+    __shared__ float4 tile[TPB];
+    const int nn = *n_noise;
+    const int first = blockIdx.x * TPB;
+    if (first >= nn) return;
+    const int last = min(nn, first + TPB) - 1;
+    const int rbeg = seg_off[seg_of_pt[noise_list[first]]];
+    const int rend = seg_off[seg_of_pt[noise_list[last]] + 1];
+    const int t = first + threadIdx.x;
+    const bool active = t < nn;
+    const int i = active ? noise_list[t] : 0;
+    const int seg = active ? seg_of_pt[i] : 0;
     const float4 me = cand[i];
-    const int my_sem = sem[i];
+    const int key = (seg << 8) | sem[i];
     float best = __builtin_inff();
     int bi = -1;
-    for (int j = beg; j < end; ++j) {
-        const float4 q = cand[j];
-        if (__float_as_int(q.w) == my_sem) {
-            const float d = sqdist(me.x, me.y, me.z, q.x, q.y, q.z);
-            if (d <= best) { best = d; bi = j; }
+    for (int base = rbeg; base < rend; base += TPB) {
+        const int j = base + threadIdx.x;
+        tile[threadIdx.x] = (j < rend) ? cand[j] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        __syncthreads();
+        const int cnt = min(TPB, rend - base);
+        if (active) {
+#pragma unroll 4
+            for (int k = 0; k < cnt; ++k) {
+                const float4 q = tile[k];
+                if (__float_as_int(q.w) == key) {
+                    const float d = sqdist(me.x, me.y, me.z, q.x, q.y, q.z);
+                    if (d <= best) { best = d; bi = base + k; }
+                }
+            }
         }
+        __syncthreads();
     }
+    if (!active) return;
     if (bi < 0) bi = last_assigned[seg];  // no assigned point of this class: binary_cuda_functions.cu:287-299
     const int id = (bi >= 0) ? lab2[bi] : -1;
     cluster_id[i] = id;
     if (id >= 0) atomicAdd(&fsize[id], 1);
 }
 
-// a16 + members CSR: one wave per final cluster walks its segment in index order, compacts its members and feeds
-// the sequential running mean M += (p - M)/N (binary_cuda_functions.cu:237-239); all lanes carry the same M.
-__global__ __launch_bounds__(TPB) void k_centers(const int* __restrict__ cluster_id, const float* __restrict__ off_xyz,
-                                                const int* __restrict__ clt_seg, const int* __restrict__ seg_off,
-                                                const int* __restrict__ n_clusters_total,
-                                                const int* __restrict__ member_start, int* __restrict__ member_idx,
-                                                float* __restrict__ centers) {
-    const int lane = lane_id();
-    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6;
-    const int n_waves = (gridDim.x * TPB) >> 6;
+// a16 + members CSR: one 64-lane workgroup per final cluster walks its segment in index order.  Each 64-point chunk
+// is compacted (ballot prefix) into LDS; lanes 0..2 then advance the sequential running mean M += (p - M)/N
+// (binary_cuda_functions.cu:237-239) of x, y, z -- three independent dependency chains in one instruction stream, the
+// IEEE division being the critical path that bit-exactness imposes.  The next chunk's loads are issued before the chain.
+constexpr int CTR_TPB = 64;
+__global__ __launch_bounds__(CTR_TPB) void k_centers(const int* __restrict__ cluster_id, const float* __restrict__ off_xyz,
+                                                    const int* __restrict__ clt_seg, const int* __restrict__ seg_off,
+                                                    const int* __restrict__ n_clusters_total,
+                                                    const int* __restrict__ member_start, int* __restrict__ member_idx,
+                                                    float* __restrict__ centers) {
+    __shared__ float s_xyz[3][CTR_TPB];
+    const int lane = threadIdx.x;
     const int C = *n_clusters_total;
-    for (int c = wave; c < C; c += n_waves) {
+    for (int c = blockIdx.x; c < C; c += gridDim.x) {
         const int seg = clt_seg[c];
         const int beg = seg_off[seg], end = seg_off[seg + 1];
-        int wpos = member_start ? member_start[c] : 0;
+        int wpos = member_start[c];
         int N = 0;
-        float mx = 0.f, my = 0.f, mz = 0.f;
-        for (int base = beg; base < end; base += 64) {
-            const int i = base + lane;
-            const bool hit = (i < end) && (cluster_id[i] == c);
-            float px = 0.f, py = 0.f, pz = 0.f;
-            if (hit) { px = off_xyz[3 * i + 0]; py = off_xyz[3 * i + 1]; pz = off_xyz[3 * i + 2]; }
-            unsigned long long mask = __ballot(hit);
-            if (member_idx && hit) member_idx[wpos + __popcll(mask & ((1ULL << lane) - 1ULL))] = i;
-            wpos += __popcll(mask);
-            while (mask) {
-                const int b = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const float x = __shfl(px, b, 64), y = __shfl(py, b, 64), z = __shfl(pz, b, 64);
-                ++N;
-                const float fn = (float)N;
-                mx = __fadd_rn(mx, __fdiv_rn(__fsub_rn(x, mx), fn));
-                my = __fadd_rn(my, __fdiv_rn(__fsub_rn(y, my), fn));
-                mz = __fadd_rn(mz, __fdiv_rn(__fsub_rn(z, mz), fn));
-            }
+        float m = 0.f;  // lane 0: x, lane 1: y, lane 2: z
+        bool hit_n = false;
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        {
+            const int i = beg + lane;
+            hit_n = (i < end) && (cluster_id[i] == c);
+            if (hit_n) { nx = off_xyz[3 * i + 0]; ny = off_xyz[3 * i + 1]; nz = off_xyz[3 * i + 2]; }
         }
-        if (lane == 0) { centers[3 * c + 0] = mx; centers[3 * c + 1] = my; centers[3 * c + 2] = mz; }
+        for (int base = beg; base < end; base += CTR_TPB) {
+            const bool hit = hit_n;
+            const float px = nx, py = ny, pz = nz;
+            {   // prefetch the next chunk
+                const int i = base + CTR_TPB + lane;
+                hit_n = (i < end) && (cluster_id[i] == c);
+                if (hit_n) { nx = off_xyz[3 * i + 0]; ny = off_xyz[3 * i + 1]; nz = off_xyz[3 * i + 2]; }
+            }
+            const unsigned long long mask = __ballot(hit);
+            const int cnt = __popcll(mask);
+            if (cnt == 0) continue;
+            const int rank = __popcll(mask & ((1ULL << lane) - 1ULL));
+            if (hit) {
+                s_xyz[0][rank] = px; s_xyz[1][rank] = py; s_xyz[2][rank] = pz;
+                if (member_idx) member_idx[wpos + rank] = base + lane;
+            }
+            wpos += cnt;
+            __syncthreads();
+            if (lane < 3) {
+                const float* v = s_xyz[lane];
+                int k = 0;
+                for (; k + 4 <= cnt; k += 4) {
+                    const float v0 = v[k], v1 = v[k + 1], v2 = v[k + 2], v3 = v[k + 3];
+                    m = __fadd_rn(m, __fdiv_rn(__fsub_rn(v0, m), (float)(N + 1)));
+                    m = __fadd_rn(m, __fdiv_rn(__fsub_rn(v1, m), (float)(N + 2)));
+                    m = __fadd_rn(m, __fdiv_rn(__fsub_rn(v2, m), (float)(N + 3)));
+                    m = __fadd_rn(m, __fdiv_rn(__fsub_rn(v3, m), (float)(N + 4)));
+                    N += 4;
+                }
+                for (; k < cnt; ++k) {
+                    ++N;
+                    m = __fadd_rn(m, __fdiv_rn(__fsub_rn(v[k], m), (float)N));
+                }
+            } else {
+                N += cnt;
+            }
+            __syncthreads();
+        }
+        if (lane < 3) centers[3 * c + lane] = m;
     }
 }
 
@@ -562,7 +634,7 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
     rc = scan_exclusive_i32(w.keep, w.newid, n, w.scan_tmp, total_kept, stream);
     if (rc != PBN_OK) return rc;
     hipLaunchKernelGGL(k_relabel, dim3(nb), dim3(TPB), 0, stream, w.lab, w.keep, w.newid, sem, w.seg_of_pt, org_xyz, n,
-                       w.lab2, cluster_id, clt_sem, w.clt_seg, w.last_assigned, w.fsize, w.noise_flag, w.cand);
+                       w.lab2, cluster_id, clt_sem, w.clt_seg, w.last_assigned, w.fsize, w.noise_flag, w.cand, w.size);
     hipLaunchKernelGGL(k_cluster_num, dim3(cdiv(n_seg, 64)), dim3(64), 0, stream, w.newid, w.seg_off, n_seg, n,
                        total_kept, cluster_num, status, n_clusters);
     if (nv_flag) {
@@ -576,8 +648,8 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
     rc = scan_exclusive_i32(w.fsize, mstart, n, w.scan_tmp, total_assigned, stream);
     if (rc != PBN_OK) return rc;
     hipLaunchKernelGGL(k_member_tail, dim3(1), dim3(64), 0, stream, mstart, total_assigned, n, total_kept);
-    const int center_blocks = 1024;  // 4096 waves, persistent over clusters
-    hipLaunchKernelGGL(k_centers, dim3(center_blocks), dim3(TPB), 0, stream, cluster_id, off_xyz, w.clt_seg, w.seg_off,
+    const int center_blocks = 2048;  // one wave per cluster, persistent over clusters
+    hipLaunchKernelGGL(k_centers, dim3(center_blocks), dim3(CTR_TPB), 0, stream, cluster_id, off_xyz, w.clt_seg, w.seg_off,
                        total_kept, mstart, member_idx, centers);
     PBN_LAUNCH_CHECK();
     return PBN_OK;

@@ -46,6 +46,9 @@ struct ConvArgs {
     int ld_in, ld_res, ld_out;
     int K, vpo, n_steps, ntiles_total;
     int n_out, relu;
+    int ksplit;          // >1: this launch writes fp32 partial sums, k_spconv_reduce applies the epilogue
+    float* partial;      // [ksplit][n_out_pad][ntiles_total*16]
+    int n_out_pad;
 };
 
 template <typename T> struct Tr;
@@ -129,8 +132,9 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     const int KS = K | 1;  // odd row pitch: conflict-free column reads of the rulebook tile
     uint4* s_w = reinterpret_cast<uint4*>(smem);                                   // 2 * NT * 64 uint4
     int* s_nbr = reinterpret_cast<int*>(smem + 2 * NT * 1024);                      // TM * KS
-    int* s_valid = s_nbr + TM * KS;                                                 // K
+    int* s_valid = s_nbr + TM * KS;                                                 // K fragment masks
     int* s_steps = s_valid + ((K + 3) & ~3);                                        // n_steps + 1 (last = count)
+    int* s_masks = s_steps + a.n_steps + 1;                                         // n_steps fragment masks
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
@@ -149,34 +153,54 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
             v = a.nbr ? a.nbr[(size_t)row * K + k] : row;
         }
         s_nbr[r * KS + k] = v;
-        if (v >= 0) s_valid[k] = 1;
     }
     __syncthreads();
-    // list of steps that touch at least one populated offset (wave 0, ordered compaction)
+    // per offset: bitmask of the 16-row fragments that have at least one neighbour there
+    constexpr int NFRAG = TM / 16;
+    for (int e = tid; e < K * NFRAG; e += CONV_TPB) {
+        const int k = e / NFRAG, fr = e - k * NFRAG;
+        int any = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) any |= (s_nbr[(fr * 16 + i) * KS + k] >= 0) ? 1 : 0;
+        if (any) atomicOr(&s_valid[k], 1 << fr);
+    }
+    __syncthreads();
+    // ordered list of the steps that touch at least one populated offset, with their fragment masks (wave 0)
     const int vpo = a.vpo;
     if (wave == 0) {
         int base = 0;
         for (int s0 = 0; s0 < a.n_steps; s0 += 64) {
             const int s = s0 + lane;
-            bool ok = false;
+            int fm = 0;
             if (s < a.n_steps) {
                 if ((vpo & 3) == 0) {
-                    ok = s_valid[s / (vpo >> 2)] != 0;
+                    fm = s_valid[s / (vpo >> 2)];
                 } else {
                     for (int g = 0; g < 4; ++g) {
                         const int ko = (s * 4 + g) / vpo;
-                        ok = ok || (ko < K && s_valid[ko] != 0);
+                        if (ko < K) fm |= s_valid[ko];
                     }
                 }
             }
+            const bool ok = fm != 0;
             const unsigned long long m = __ballot(ok);
-            if (ok) s_steps[base + __popcll(m & ((1ULL << lane) - 1ULL))] = s;
+            if (ok) {
+                const int pos = base + __popcll(m & ((1ULL << lane) - 1ULL));
+                s_steps[pos] = s;
+                s_masks[pos] = fm;
+            }
             base += __popcll(m);
         }
         if (lane == 0) s_steps[a.n_steps] = base;
     }
     __syncthreads();
-    const int ns = s_steps[a.n_steps];
+    int ns = s_steps[a.n_steps];
+    int s_lo = 0;
+    if (a.ksplit > 1) {  // this workgroup reduces only its slice of the step list
+        s_lo = (int)((long long)ns * blockIdx.z / a.ksplit);
+        ns = (int)((long long)ns * (blockIdx.z + 1) / a.ksplit);
+    }
+    const unsigned my_bits = ((1u << NF) - 1u) << (wave * NF);
 
     f32x4 acc[NF][NT];
 #pragma unroll
@@ -189,17 +213,19 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     const int g = lane >> 4, rl = lane & 15;
     constexpr int WREGS = (NT * 64 + CONV_TPB - 1) / CONV_TPB;
 
-    auto load_x = [&](int s, uint4 (&x)[NF]) {
+    auto load_x = [&](int s, unsigned fm, uint4 (&x)[NF]) {
         const int v = s * 4 + g;
         int ko, cv;
         if ((vpo & 3) == 0) { const int q = vpo >> 2; ko = s / q; cv = (s - ko * q) * 4 + g; }
         else { ko = v / vpo; cv = v - ko * vpo; }
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const int r = wave * RW + f * 16 + rl;
-            const int src = (ko < K) ? s_nbr[r * KS + ko] : -1;
             x[f] = make_uint4(0u, 0u, 0u, 0u);
-            if (src >= 0) x[f] = *reinterpret_cast<const uint4*>(in + (size_t)src * a.ld_in + cv * ELEMS);
+            if ((fm >> (wave * NF + f)) & 1u) {
+                const int r = wave * RW + f * 16 + rl;
+                const int src = (ko < K) ? s_nbr[r * KS + ko] : -1;
+                if (src >= 0) x[f] = *reinterpret_cast<const uint4*>(in + (size_t)src * a.ld_in + cv * ELEMS);
+            }
         }
     };
     auto load_w = [&](int s, uint4 (&wr)[WREGS]) {
@@ -217,31 +243,53 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
         }
     };
 
-    if (ns > 0) {
+    if (ns > s_lo) {
         uint4 xcur[NF], xnext[NF], wr[WREGS];
-        load_w(s_steps[0], wr);
-        load_x(s_steps[0], xcur);
+        unsigned fcur = (unsigned)s_masks[s_lo], fnext = 0;
+        load_w(s_steps[s_lo], wr);
+        load_x(s_steps[s_lo], fcur, xcur);
         store_w(0, wr);
         __syncthreads();
-        for (int si = 0; si < ns; ++si) {
-            const int cur = si & 1;
+        for (int si = s_lo; si < ns; ++si) {
+            const int cur = (si - s_lo) & 1;
             const bool more = si + 1 < ns;
             if (more) {
                 const int sn = s_steps[si + 1];
+                fnext = (unsigned)s_masks[si + 1];
                 load_w(sn, wr);
-                load_x(sn, xnext);
+                load_x(sn, fnext, xnext);
             }
+            if (fcur & my_bits) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const uint4 wf = s_w[cur * NT * 64 + t * 64 + lane];
+                for (int t = 0; t < NT; ++t) {
+                    const uint4 wf = s_w[cur * NT * 64 + t * 64 + lane];
 #pragma unroll
-                for (int f = 0; f < NF; ++f) mfma_step<T>(wf, xcur[f], acc[f][t]);
+                    for (int f = 0; f < NF; ++f)
+                        if ((fcur >> (wave * NF + f)) & 1u) mfma_step<T>(wf, xcur[f], acc[f][t]);
+                }
             }
             if (more) store_w(cur ^ 1, wr);
             __syncthreads();
 #pragma unroll
             for (int f = 0; f < NF; ++f) xcur[f] = xnext[f];
+            fcur = fnext;
         }
+    }
+
+    if (a.ksplit > 1) {  // raw fp32 partial sums, tile-position rows; the epilogue runs in k_spconv_reduce
+        const int ldp = a.ntiles_total * 16;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const int p = row0 + wave * RW + f * 16 + rl;
+            if (p >= n) continue;
+            float* dst = a.partial + ((size_t)blockIdx.z * a.n_out_pad + p) * ldp;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c0 = (tile0 + t) * 16 + g * 4;
+                *reinterpret_cast<float4*>(dst + c0) = make_float4(acc[f][t][0], acc[f][t][1], acc[f][t][2], acc[f][t][3]);
+            }
+        }
+        return;
     }
 
     // epilogue: lane holds channels c0..c0+3 of output row (wave*RW + f*16 + rl)
@@ -276,35 +324,84 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     }
 }
 
+// second pass of a split-K launch: fixed-order sum of the partial slabs + the fused epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void k_spconv_reduce(const ConvArgs a) {
+    const int ldp = a.ntiles_total * 16;
+    const int vec_per_row = ldp >> 2;
+    const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)n * vec_per_row) return;
+    const int p = (int)(e / vec_per_row), c0 = (int)(e - (long long)p * vec_per_row) * 4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < a.ksplit; ++z) {
+        const float4 t = *reinterpret_cast<const float4*>(a.partial + ((size_t)z * a.n_out_pad + p) * ldp + c0);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    const int orow = a.row_perm ? a.row_perm[p] : p;
+    if (a.scale) {
+        const float4 sc = *reinterpret_cast<const float4*>(a.scale + c0);
+        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+    }
+    if (a.shift) {
+        const float4 sh = *reinterpret_cast<const float4*>(a.shift + c0);
+        v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+    }
+    if (a.residual) v += load4<T>(reinterpret_cast<const T*>(a.residual) + (size_t)orow * a.ld_res + c0);
+    if (a.relu) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    store4<T>(reinterpret_cast<T*>(a.out) + (size_t)orow * a.ld_out + c0, v);
+}
+
 template <typename T, int RW, int NT>
-int launch_one(const ConvArgs& a, int ngroups, hipStream_t stream) {
+int launch_one(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes, hipStream_t stream) {
     constexpr int TM = 4 * RW;
     const int KS = a.K | 1;
-    const size_t lds = 2 * NT * 1024 + sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + a.n_steps + 1);
+    const size_t lds = 2 * NT * 1024 + sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 2 * (size_t)a.n_steps + 1);
     if (lds > 160 * 1024) return PBN_ERR_UNSUPPORTED;
     auto kern = k_spconv<T, RW, NT>;
     if (lds > 64 * 1024)
         PBN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tiles = cdiv(a.n_out, TM);
-    hipLaunchKernelGGL(kern, dim3(tiles, ngroups), dim3(CONV_TPB), lds, stream, a);
+    // split the reduction over more workgroups when the launch would leave most of the 256 CUs idle
+    // (stride-8/16 levels: a few hundred to a few thousand rows but 27 x 256..384 deep reductions)
+    a.ksplit = 1;
+    a.partial = nullptr;
+    a.n_out_pad = tiles * TM;
+    const long long wgs = (long long)tiles * ngroups;
+    if (workspace && wgs < 384 && a.n_steps >= 8) {
+        long long want = (768 + wgs - 1) / wgs;
+        const long long by_steps = a.n_steps / 4;
+        const long long by_ws = (long long)(workspace_bytes / ((size_t)a.n_out_pad * a.ntiles_total * 16 * sizeof(float)));
+        if (want > by_steps) want = by_steps;
+        if (want > by_ws) want = by_ws;
+        if (want > 32) want = 32;
+        if (want > 1) { a.ksplit = (int)want; a.partial = workspace; }
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, ngroups, a.ksplit), dim3(CONV_TPB), lds, stream, a);
+    if (a.ksplit > 1) {
+        const long long total = (long long)a.n_out * (a.ntiles_total * 4);
+        hipLaunchKernelGGL(k_spconv_reduce<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream, a);
+    }
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
 
 template <typename T, int RW>
-int launch_nt(const ConvArgs& a, hipStream_t stream) {
+int launch_nt(const ConvArgs& a, float* ws, size_t wsb, hipStream_t stream) {
     const int ntt = a.ntiles_total;
-    if (ntt % 8 == 0) return launch_one<T, RW, 8>(a, ntt / 8, stream);
-    if (ntt % 6 == 0) return launch_one<T, RW, 6>(a, ntt / 6, stream);
-    if (ntt % 4 == 0) return launch_one<T, RW, 4>(a, ntt / 4, stream);
-    if (ntt % 2 == 0) return launch_one<T, RW, 2>(a, ntt / 2, stream);
-    return launch_one<T, RW, 1>(a, ntt, stream);
+    if (ntt % 8 == 0) return launch_one<T, RW, 8>(a, ntt / 8, ws, wsb, stream);
+    if (ntt % 6 == 0) return launch_one<T, RW, 6>(a, ntt / 6, ws, wsb, stream);
+    if (ntt % 4 == 0) return launch_one<T, RW, 4>(a, ntt / 4, ws, wsb, stream);
+    if (ntt % 2 == 0) return launch_one<T, RW, 2>(a, ntt / 2, ws, wsb, stream);
+    return launch_one<T, RW, 1>(a, ntt, ws, wsb, stream);
 }
 
 template <typename T>
-int launch_t(const ConvArgs& a, int rows_per_wave, hipStream_t stream) {
-    if (rows_per_wave == 32) return launch_nt<T, 32>(a, stream);
-    return launch_nt<T, 16>(a, stream);
+int launch_t(const ConvArgs& a, int rows_per_wave, float* ws, size_t wsb, hipStream_t stream) {
+    if (rows_per_wave == 32) return launch_nt<T, 32>(a, ws, wsb, stream);
+    return launch_nt<T, 16>(a, ws, wsb, stream);
 }
 
 // ---- row gather: out[i, :] = in[idx[i], :]  (voxel -> point, PBNet.py:130-134) ----------------------------------
@@ -326,7 +423,8 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, const int32_t*
                                   const int32_t* row_perm, const int32_t* n_out_dev, int n_out, const void* w_packed,
                                   int vecs_per_offset, int n_steps, int cout_padded, const float* scale,
                                   const float* shift, const void* residual, int ld_res, int relu, void* out_feat,
-                                  int ld_out, int dtype, int rows_per_wave, pbn_stream_t stream_) {
+                                  int ld_out, int dtype, int rows_per_wave, void* workspace, size_t workspace_bytes,
+                                  pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_out < 0 || n_offsets < 1 || vecs_per_offset < 1 || n_steps < 1 || cout_padded < 16 || (cout_padded & 15))
         return PBN_ERR_ARG;
@@ -343,11 +441,14 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, const int32_t*
     a.shift = shift; a.residual = residual; a.out = out_feat; a.ld_in = ld_in; a.ld_res = ld_res; a.ld_out = ld_out;
     a.K = n_offsets; a.vpo = vecs_per_offset; a.n_steps = n_steps; a.ntiles_total = cout_padded / 16; a.n_out = n_out;
     a.relu = relu;
+    a.ksplit = 1; a.partial = nullptr; a.n_out_pad = 0;
+    float* ws = reinterpret_cast<float*>(workspace);
+    if (((uintptr_t)workspace) & 15) ws = nullptr;
     if (rows_per_wave != 16 && rows_per_wave != 32) rows_per_wave = (n_out >= 64 * 1024) ? 32 : 16;
     switch (dtype) {
-        case PBN_F32: return launch_t<float>(a, rows_per_wave, stream);
-        case PBN_BF16: return launch_t<__hip_bfloat16>(a, rows_per_wave, stream);
-        case PBN_F16: return launch_t<__half>(a, rows_per_wave, stream);
+        case PBN_F32: return launch_t<float>(a, rows_per_wave, ws, workspace_bytes, stream);
+        case PBN_BF16: return launch_t<__hip_bfloat16>(a, rows_per_wave, ws, workspace_bytes, stream);
+        case PBN_F16: return launch_t<__half>(a, rows_per_wave, ws, workspace_bytes, stream);
         default: return PBN_ERR_ARG;
     }
 }
