@@ -158,6 +158,13 @@ int pbn_spconv_forward(const void* in_feat, int ld_in, const int32_t* nbr, int n
 int pbn_gather_rows(const void* in, int ld_in_bytes, const int64_t* idx, int n, int row_bytes, void* out,
                     int ld_out_bytes, pbn_stream_t stream);
 
+/* Per-batch global max and/or average pooling of a slab whose rows are grouped by batch index
+ * (MinkowskiGlobalMaxPooling / MinkowskiGlobalAvgPooling of the score branch, network/PBNet.py:67-68,274-276).
+ * seg_start int32[n_seg+1] row offsets; out_max / out_avg f32 [n_seg, channels] (either may be NULL).
+ * An empty segment yields -inf / NaN exactly like the reductions it replaces.  Deterministic. */
+int pbn_segment_pool(const void* feats, int ld, int channels, int dtype, const int32_t* seg_start, int n_seg,
+                     float* out_max, float* out_avg, pbn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

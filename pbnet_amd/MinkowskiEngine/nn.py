@@ -62,6 +62,23 @@ def _batch_index(x):
     return b, int(b.max().item()) + 1 if b.numel() else 0
 
 
+def segment_pool(feats, batch_sorted, n_batch, want_max=True, want_avg=True):
+    """Global max / avg pooling per batch index for rows GROUPED by ascending batch index (pbn_segment_pool).
+    Returns fp32 [n_batch, C] tensors (None for the one not requested)."""
+    from .. import _native as N
+    from .conv import _DT
+    assert feats.stride(1) == 1
+    seg_start = torch.searchsorted(batch_sorted.to(torch.int32).contiguous(),
+                                   torch.arange(n_batch + 1, dtype=torch.int32, device=feats.device)).to(torch.int32)
+    c = feats.shape[1]
+    mx = torch.empty(n_batch, c, dtype=torch.float32, device=feats.device) if want_max else None
+    av = torch.empty(n_batch, c, dtype=torch.float32, device=feats.device) if want_avg else None
+    rc = N.lib().pbn_segment_pool(N.c_vp(feats.data_ptr()), feats.stride(0), c, _DT[feats.dtype], N.ptr(seg_start),
+                                  int(n_batch), N.ptr(mx), N.ptr(av), N.current_stream())
+    N.check(rc, "pbn_segment_pool")
+    return mx, av
+
+
 class _GlobalPool(nn.Module):
     MODE = "avg"
 

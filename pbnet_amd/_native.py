@@ -39,6 +39,7 @@ SIGNATURES = {
     "pbn_spconv_forward": (c_int, [c_vp, c_int, c_i32p, c_int, c_i32p, c_i32p, c_int, c_vp, c_int, c_int, c_int,
                                    c_f32p, c_f32p, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "pbn_gather_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
+    "pbn_segment_pool": (c_int, [c_vp, c_int, c_int, c_int, c_i32p, c_int, c_f32p, c_f32p, c_vp]),
 }
 
 ERRORS = {-1: "PBN_ERR_ARG", -2: "PBN_ERR_WORKSPACE", -3: "PBN_ERR_HIP", -4: "PBN_ERR_RANGE", -5: "PBN_ERR_UNSUPPORTED"}

@@ -3,8 +3,10 @@
 // Replaces the Solver pipeline of /root/reference/lib/PB_lib/src/pbnet/{cluster.cu,binary.cu,binary_cuda_functions.cu}
 // with a batch-of-segments pipeline that never leaves the device and never materialises the adjacency:
 //
-//   seg offsets -> uniform grid hash (cell = 1.0625 r) -> cell-sorted point slab -> exact r-ball count (+HP flag)
-//   -> lock-free union-find over HP-HP pairs (min-index roots) -> border LP = max adjacent seed
+//   seg offsets -> uniform grid hash (cell = 0.5625 r: any two points of one cell are within r) -> cell-sorted slab
+//   -> exact r-ball count over the 5x5x5 neighbourhood (+HP flag) -> lock-free union-find (min-index roots) driven by
+//   CELLS, not pairs: HPs of a cell are chained to the cell's representative, two cells need ONE witnessed edge
+//   -> border LP = max adjacent seed (one witness per cell)
 //   -> sizes -> keep flags -> scan = final ids -> exact NN for unassigned points -> ordered members + centres
 //
 // Determinism: every output is a function of the input only (atomics are used on integers where the result is
@@ -21,7 +23,8 @@ namespace {
 constexpr int TPB = 256;
 constexpr unsigned long long EMPTY_KEY = ~0ULL;
 constexpr int CELL_BIAS = 32768;
-constexpr float CELL_CLAMP = 32766.0f;
+constexpr float CELL_CLAMP = 32764.0f;  // +-2 neighbour offsets must stay inside 16 bits
+constexpr int CELL_R = 2;                // cells of side 0.5625 r: r-neighbours are at most 2 cells away per axis
 constexpr int BIG = 0x7f7f7f7f;  // memset(0x7f) pattern: "no seed yet"
 
 // lib/PB_lib/src/pbnet/binary.cu:229 ("mean count from HAIS"), indexed by sem-2
@@ -122,61 +125,76 @@ __global__ __launch_bounds__(TPB) void k_cell_insert(const float* __restrict__ o
 __global__ __launch_bounds__(TPB) void k_cell_scatter(const float* __restrict__ off_xyz, int n,
                                                      const int* __restrict__ slot_of_pt, const int* __restrict__ hstart,
                                                      int* __restrict__ hcursor, const int* __restrict__ seg_of_pt,
-                                                     float4* __restrict__ spt, int* __restrict__ sseg) {
+                                                     float4* __restrict__ spt, int* __restrict__ sseg,
+                                                     int* __restrict__ sslot) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     const int slot = slot_of_pt[i];
     const int pos = hstart[slot] + atomicAdd(&hcursor[slot], 1);
     spt[pos] = make_float4(off_xyz[3 * i + 0], off_xyz[3 * i + 1], off_xyz[3 * i + 2], __int_as_float(i));
     sseg[pos] = seg_of_pt[i];
+    sslot[pos] = slot;
 }
 
-// Enumerate the 27 cells around point (x,y,z) of segment seg; F(beg, end) is called per occupied cell.
+__device__ __forceinline__ bool cell_trusted(int cx, int cy, int cz) {
+    // a clamped border cell collects arbitrarily distant points: its members are NOT known to be within r of each other
+    const int lim = (int)CELL_CLAMP;
+    return cx > -lim && cx < lim && cy > -lim && cy < lim && cz > -lim && cz < lim;
+}
+
+// Enumerate the 5x5x5 cells around point (x,y,z) of segment seg; f(beg, end, slot, trusted, same) per occupied cell.
 template <typename F>
 __device__ __forceinline__ void for_each_neighbour_cell(float x, float y, float z, int seg, float inv_cell,
                                                         const unsigned long long* __restrict__ hkeys, unsigned hmask,
                                                         const int* __restrict__ hstart, const int* __restrict__ hcount,
                                                         F&& f) {
     const int cx = cell_coord(x, inv_cell), cy = cell_coord(y, inv_cell), cz = cell_coord(z, inv_cell);
-    for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
+    for (int dz = -CELL_R; dz <= CELL_R; ++dz)
+        for (int dy = -CELL_R; dy <= CELL_R; ++dy)
+            for (int dx = -CELL_R; dx <= CELL_R; ++dx) {
                 const int slot = hash_lookup(hkeys, hmask, pack_key(seg, cx + dx, cy + dy, cz + dz));
                 if (slot < 0) continue;
                 const int beg = hstart[slot];
-                f(beg, beg + hcount[slot]);
+                f(beg, beg + hcount[slot], slot, cell_trusted(cx + dx, cy + dy, cz + dz), (dx | dy | dz) == 0);
             }
 }
 
-// ---- a10/a12: exact r-ball population (self excluded) ; thread per cell-sorted position --------------------------
+// ---- a10/a12: exact r-ball population (self excluded); FOUR adjacent lanes per cell-sorted position share the
+// candidate stream (lane q takes candidates beg+q, beg+q+4, ...) and combine with two shuffles
+constexpr int CNT_Q = 4;
 __global__ __launch_bounds__(TPB) void k_count(const float4* __restrict__ spt, const int* __restrict__ sseg, int n,
                                               float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
                                               unsigned hmask, const int* __restrict__ hstart,
                                               const int* __restrict__ hcount, int* __restrict__ den) {
-    const int p = blockIdx.x * TPB + threadIdx.x;
-    if (p >= n) return;
+    const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
+    int p = (int)(t / CNT_Q);
+    const int q = (int)(t % CNT_Q);
+    const bool live = p < n;
+    if (!live) p = n - 1;  // keep the quad complete for the shuffles
     const float4 me = spt[p];
     int cnt = 0;
-    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount, [&](int beg, int end) {
-        int j = beg;
-        for (; j + 4 <= end; j += 4) {  // 4 independent loads in flight
-            const float4 q0 = spt[j], q1 = spt[j + 1], q2 = spt[j + 2], q3 = spt[j + 3];
+    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount,
+                            [&](int beg, int end, int, bool, bool) {
+        int j = beg + q;
+        for (; j + CNT_Q < end; j += 2 * CNT_Q) {  // two independent loads in flight
+            const float4 q0 = spt[j], q1 = spt[j + CNT_Q];
             cnt += (sqdist(me.x, me.y, me.z, q0.x, q0.y, q0.z) <= r2) ? 1 : 0;
             cnt += (sqdist(me.x, me.y, me.z, q1.x, q1.y, q1.z) <= r2) ? 1 : 0;
-            cnt += (sqdist(me.x, me.y, me.z, q2.x, q2.y, q2.z) <= r2) ? 1 : 0;
-            cnt += (sqdist(me.x, me.y, me.z, q3.x, q3.y, q3.z) <= r2) ? 1 : 0;
         }
-        for (; j < end; ++j) {
-            const float4 q = spt[j];
-            cnt += (sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) ? 1 : 0;
+        for (; j < end; j += CNT_Q) {
+            const float4 q0 = spt[j];
+            cnt += (sqdist(me.x, me.y, me.z, q0.x, q0.y, q0.z) <= r2) ? 1 : 0;
         }
     });
-    den[__float_as_int(me.w)] = cnt - 1;  // binary_cuda_functions.cu:88
+    cnt += __shfl_xor(cnt, 1, 64);
+    cnt += __shfl_xor(cnt, 2, 64);
+    if (live && q == 0) den[__float_as_int(me.w)] = cnt - 1;  // binary_cuda_functions.cu:88
 }
 
 // tag the HP flag into bit 31 of the index word of the sorted slab; init union-find parents
 __global__ __launch_bounds__(TPB) void k_tag_hp(float4* __restrict__ spt, int n, const int* __restrict__ den, int min_pts,
-                                               int* __restrict__ parent, int* __restrict__ lab) {
+                                               int* __restrict__ parent, int* __restrict__ lab,
+                                               const int* __restrict__ sslot, int* __restrict__ cell_rep) {
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= n) return;
     const int i = __float_as_int(spt[p].w);
@@ -184,6 +202,7 @@ __global__ __launch_bounds__(TPB) void k_tag_hp(float4* __restrict__ spt, int n,
     spt[p].w = __int_as_float(i | (hp ? (int)0x80000000 : 0));
     parent[i] = i;
     lab[i] = -1;
+    if (hp) atomicMin(&cell_rep[sslot[p]], i);  // representative HP of the cell (BIG = the cell has no HP)
 }
 
 // ---- lock-free union-find; roots are always the smallest index of their set -----------------------------------
@@ -212,26 +231,52 @@ __device__ __forceinline__ int uf_union(int* __restrict__ parent, int a, int b) 
     }
 }
 
-// a13: connected components of the HP graph; each undirected edge is handled by its larger endpoint
+// a13: connected components of the HP graph, cell driven.
+//  * own cell, trusted: every HP of the cell is within r of every other -> one union with the cell representative;
+//  * other trusted cell: its HPs form one set already (their own chain), so ONE witnessed edge (first HP within r)
+//    merges the two cells, and the whole cell is skipped when its representative already shares our root;
+//  * untrusted (clamped border) cells fall back to pairwise unions, each edge handled by its larger endpoint.
+// Every HP-HP edge (i,j) ends with find(i) == find(j): either both cells are trusted and chained to representatives
+// that some witness joined, or the pairwise fallback handled the edge itself.
 __global__ __launch_bounds__(TPB) void k_union(const float4* __restrict__ spt, const int* __restrict__ sseg, int n,
                                               float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
                                               unsigned hmask, const int* __restrict__ hstart,
-                                              const int* __restrict__ hcount, int* parent) {
+                                              const int* __restrict__ hcount, int* parent,
+                                              const int* __restrict__ cell_rep) {
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= n) return;
     const float4 me = spt[p];
     const int wi = __float_as_int(me.w);
     if (wi >= 0) return;  // LP: never expands (binary_cuda_functions.cu:209)
     const int i = wi & 0x7fffffff;
-    int ri = uf_find(parent, i);
-    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount, [&](int beg, int end) {
+    int ri = i;
+    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount,
+                            [&](int beg, int end, int slot, bool trusted, bool same) {
+        const int rep = cell_rep[slot];
+        if (rep == BIG) return;  // no HP in that cell
+        if (trusted) {
+            if (same) {
+                if (rep != i) ri = uf_union(parent, ri, rep);
+                return;
+            }
+            // plain (possibly stale) read: a stale parent is a former ancestor, i.e. provably the same set
+            if (rep == ri || parent[rep] == ri) return;
+            ri = uf_find(parent, ri);
+            if (uf_find(parent, rep) == ri) return;
+            for (int j = beg; j < end; ++j) {
+                const float4 q = spt[j];
+                if (__float_as_int(q.w) < 0 && sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) {
+                    ri = uf_union(parent, ri, __float_as_int(q.w) & 0x7fffffff);
+                    return;
+                }
+            }
+            return;
+        }
         for (int j = beg; j < end; ++j) {
             const float4 q = spt[j];
             const int wj = __float_as_int(q.w);
             const int jj = wj & 0x7fffffff;
             if (wj < 0 && jj < i && sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) {
-                // Shortcut on a plain (L1-cached, possibly stale) read: a stale parent is still a former ancestor,
-                // i.e. a member of the same set, so equality proves "already merged"; inequality only costs a union.
                 if (parent[jj] != ri) ri = uf_union(parent, ri, jj);
             }
         }
@@ -265,35 +310,48 @@ __global__ __launch_bounds__(TPB) void k_hp_seed_general(const float4* __restric
 
 // a13 (border rule): an LP within r of HPs takes the LAST cluster that reached it = the largest seed index among
 // clusters (component of an adjacent HP, class of the LP) -- binary.cu:206-209.  `root` holds component roots of HPs.
+// All HPs of a trusted cell share one component, so the cell contributes one candidate seed: it is skipped when that
+// seed cannot raise the maximum, taken without any distance test in the LP's own cell, and otherwise needs one witness.
 __global__ __launch_bounds__(TPB) void k_border(const float4* __restrict__ spt, const int* __restrict__ sseg, int n,
                                                float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
                                                unsigned hmask, const int* __restrict__ hstart,
                                                const int* __restrict__ hcount, const int* __restrict__ sem, int general,
                                                const int* __restrict__ semseed, const int* __restrict__ root,
-                                               int* __restrict__ lab) {
+                                               int* __restrict__ lab, const int* __restrict__ cell_rep) {
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= n) return;
     const float4 me = spt[p];
     const int wi = __float_as_int(me.w);
     if (wi < 0) return;  // HP
     const int i = wi;
-    const int my_sem = sem[i];
+    const int my_cls = cls_of(sem[i]);
     int best = -1;
-    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount, [&](int beg, int end) {
+    auto seed_of = [&](int hp_index) {
+        int s = root[hp_index];
+        if (general) {
+            s = semseed[(size_t)my_cls * n + s];
+            if (s == BIG) s = -1;
+        }
+        return s;
+    };
+    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount,
+                            [&](int beg, int end, int slot, bool trusted, bool same) {
+        const int rep = cell_rep[slot];
+        if (rep == BIG) return;
+        if (trusted) {
+            const int s = seed_of(rep);
+            if (s <= best) return;
+            if (same) { best = s; return; }
+            for (int j = beg; j < end; ++j) {
+                const float4 q = spt[j];
+                if (__float_as_int(q.w) < 0 && sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) { best = s; return; }
+            }
+            return;
+        }
         for (int j = beg; j < end; ++j) {
             const float4 q = spt[j];
             const int wj = __float_as_int(q.w);
-            if (wj < 0 && sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) {
-                const int jj = wj & 0x7fffffff;
-                int s;
-                if (general) {
-                    s = semseed[(size_t)cls_of(my_sem) * n + root[jj]];
-                    if (s == BIG) s = -1;
-                } else {
-                    s = root[jj];
-                }
-                best = max(best, s);
-            }
+            if (wj < 0 && sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) best = max(best, seed_of(wj & 0x7fffffff));
         }
     });
     lab[i] = best;
@@ -387,48 +445,39 @@ __global__ __launch_bounds__(TPB) void k_compact_noise(const int* __restrict__ n
 }
 
 // a15: exact nearest assigned point of the same class, ORIGINAL coordinates, ties -> highest index
-// (binary_cuda_functions.cu:258-302).  Thread per unassigned point (compacted list, ascending index).  A workgroup's
-// points span a contiguous run of segments; that run is streamed once through LDS in ascending index, so the `<=`
-// update reproduces the reference's scan order while every candidate costs one broadcast ds_read instead of a
-// dependent global load.  cand.w = (segment << 8 | class) for assigned points, -1 otherwise.
+// (binary_cuda_functions.cu:258-302: ascending scan with `<=`, i.e. the lexicographic optimum (min d2, max index)).
+// One WAVE per unassigned point: the 64 lanes stride over the point's segment with coalesced 16-byte candidate reads,
+// keep a private optimum and combine with shuffles -- order independent, hence identical to the sequential scan.
+// cand.w = (segment << 8 | class) for assigned points, -1 otherwise.
 __global__ __launch_bounds__(TPB) void k_noise_nn(const int* __restrict__ noise_list, const int* __restrict__ n_noise,
                                                  const float4* __restrict__ cand, const int* __restrict__ sem,
                                                  const int* __restrict__ seg_of_pt, const int* __restrict__ seg_off,
                                                  const int* __restrict__ lab2, const int* __restrict__ last_assigned,
                                                  int* __restrict__ cluster_id, int* __restrict__ fsize) {
-    __shared__ float4 tile[TPB];
-    const int nn = *n_noise;
-    const int first = blockIdx.x * TPB;
-    if (first >= nn) return;
-    const int last = min(nn, first + TPB) - 1;
-    const int rbeg = seg_off[seg_of_pt[noise_list[first]]];
-    const int rend = seg_off[seg_of_pt[noise_list[last]] + 1];
-    const int t = first + threadIdx.x;
-    const bool active = t < nn;
-    const int i = active ? noise_list[t] : 0;
-    const int seg = active ? seg_of_pt[i] : 0;
+    const int lane = lane_id();
+    const int w = (int)(((long long)blockIdx.x * TPB + threadIdx.x) >> 6);
+    if (w >= *n_noise) return;
+    const int i = noise_list[w];
+    const int seg = seg_of_pt[i];
+    const int beg = seg_off[seg], end = seg_off[seg + 1];
     const float4 me = cand[i];
     const int key = (seg << 8) | sem[i];
     float best = __builtin_inff();
     int bi = -1;
-    for (int base = rbeg; base < rend; base += TPB) {
-        const int j = base + threadIdx.x;
-        tile[threadIdx.x] = (j < rend) ? cand[j] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        __syncthreads();
-        const int cnt = min(TPB, rend - base);
-        if (active) {
-#pragma unroll 4
-            for (int k = 0; k < cnt; ++k) {
-                const float4 q = tile[k];
-                if (__float_as_int(q.w) == key) {
-                    const float d = sqdist(me.x, me.y, me.z, q.x, q.y, q.z);
-                    if (d <= best) { best = d; bi = base + k; }
-                }
-            }
+    for (int j = beg + lane; j < end; j += 64) {
+        const float4 q = cand[j];
+        if (__float_as_int(q.w) == key) {
+            const float d = sqdist(me.x, me.y, me.z, q.x, q.y, q.z);
+            if (d <= best) { best = d; bi = j; }  // ascending j per lane
         }
-        __syncthreads();
     }
-    if (!active) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi >= 0 && (bi < 0 || ob < best || (ob == best && oi > bi))) { best = ob; bi = oi; }
+    }
+    if (lane != 0) return;
     if (bi < 0) bi = last_assigned[seg];  // no assigned point of this class: binary_cuda_functions.cu:287-299
     const int id = (bi >= 0) ? lab2[bi] : -1;
     cluster_id[i] = id;
@@ -511,7 +560,7 @@ __global__ void k_member_tail(int* __restrict__ member_start, const int* __restr
 }
 
 struct Workspace {
-    int *seg_off, *seg_of_pt, *slot_of_pt, *hcount, *hstart, *hcursor, *sseg, *parent, *lab, *root, *semseed, *size,
+    int *seg_off, *seg_of_pt, *slot_of_pt, *hcount, *hstart, *hcursor, *sseg, *sslot, *cell_rep, *parent, *lab, *root, *semseed, *size,
         *keep, *newid, *lab2, *clt_seg, *last_assigned, *fsize, *noise_flag, *noise_pos, *noise_list, *scan_tmp,
         *scalars, *mstart_tmp;
     unsigned long long* hkeys;
@@ -538,6 +587,8 @@ size_t carve(Carver& cv, Workspace& w, int n, int n_seg, int general) {
     w.seg_of_pt = cv.take<int>(N);
     w.slot_of_pt = cv.take<int>(N);
     w.sseg = cv.take<int>(N);
+    w.sslot = cv.take<int>(N);
+    w.cell_rep = cv.take<int>(w.hcap);
     w.parent = cv.take<int>(N);
     w.lab = cv.take<int>(N);
     w.root = cv.take<int>(N);
@@ -592,7 +643,7 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
     carve(cv, w, n, n_seg, general);
     if (!cv.ok) return PBN_ERR_WORKSPACE;
 
-    const float cell = radius * 1.0625f;  // > r so that every r-neighbour lies in the 27 surrounding cells
+    const float cell = radius * 0.5625f;  // diagonal 0.974 r: same cell => within r; r-neighbours within +-2 cells
     const float inv_cell = 1.0f / cell;
     const float r2 = radius * radius;      // binary_cuda_functions.cu:85 (fp32 product)
     const unsigned hmask = w.hcap - 1;
@@ -606,6 +657,7 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
     PBN_HIP_CHECK(hipMemsetAsync(w.hkeys, 0xff, sizeof(unsigned long long) * w.hcap, stream));
     PBN_HIP_CHECK(hipMemsetAsync(w.hcount, 0, sizeof(int) * w.hcap, stream));
     PBN_HIP_CHECK(hipMemsetAsync(w.hcursor, 0, sizeof(int) * w.hcap, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(w.cell_rep, 0x7f, sizeof(int) * w.hcap, stream));
     PBN_HIP_CHECK(hipMemsetAsync(w.size, 0, sizeof(int) * (size_t)n, stream));
     PBN_HIP_CHECK(hipMemsetAsync(w.fsize, 0, sizeof(int) * (size_t)n, stream));
     PBN_HIP_CHECK(hipMemsetAsync(w.last_assigned, 0xff, sizeof(int) * ((size_t)n_seg + 1), stream));
@@ -617,18 +669,18 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
     int rc = scan_exclusive_i32(w.hcount, w.hstart, (int)w.hcap, w.scan_tmp, nullptr, stream);
     if (rc != PBN_OK) return rc;
     hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(TPB), 0, stream, off_xyz, n, w.slot_of_pt, w.hstart, w.hcursor,
-                       w.seg_of_pt, w.spt, w.sseg);
-    hipLaunchKernelGGL(k_count, dim3(nb), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+                       w.seg_of_pt, w.spt, w.sseg, w.sslot);
+    hipLaunchKernelGGL(k_count, dim3(cdiv((long long)n * CNT_Q, TPB)), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
                        w.hstart, w.hcount, den);
-    hipLaunchKernelGGL(k_tag_hp, dim3(nb), dim3(TPB), 0, stream, w.spt, n, den, min_pts, w.parent, w.lab);
+    hipLaunchKernelGGL(k_tag_hp, dim3(nb), dim3(TPB), 0, stream, w.spt, n, den, min_pts, w.parent, w.lab, w.sslot, w.cell_rep);
     hipLaunchKernelGGL(k_union, dim3(nb), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
-                       w.hstart, w.hcount, w.parent);
+                       w.hstart, w.hcount, w.parent, w.cell_rep);
     hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, stream, w.spt, n, w.parent, sem, general, w.semseed, w.lab);
     hipLaunchKernelGGL(k_copy_i32, dim3(nb), dim3(TPB), 0, stream, w.lab, w.root, n);
     if (general)
         hipLaunchKernelGGL(k_hp_seed_general, dim3(nb), dim3(TPB), 0, stream, w.spt, n, sem, w.semseed, w.lab);
     hipLaunchKernelGGL(k_border, dim3(nb), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
-                       w.hstart, w.hcount, sem, general, w.semseed, w.root, w.lab);
+                       w.hstart, w.hcount, sem, general, w.semseed, w.root, w.lab, w.cell_rep);
     hipLaunchKernelGGL(k_sizes, dim3(nb), dim3(TPB), 0, stream, w.lab, n, w.size);
     hipLaunchKernelGGL(k_keep, dim3(nb), dim3(TPB), 0, stream, w.lab, w.size, sem, n, para_f, w.keep);
     rc = scan_exclusive_i32(w.keep, w.newid, n, w.scan_tmp, total_kept, stream);
@@ -641,7 +693,7 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
         rc = scan_exclusive_i32(w.noise_flag, w.noise_pos, n, w.scan_tmp, n_noise, stream);
         if (rc != PBN_OK) return rc;
         hipLaunchKernelGGL(k_compact_noise, dim3(nb), dim3(TPB), 0, stream, w.noise_flag, w.noise_pos, n, w.noise_list);
-        hipLaunchKernelGGL(k_noise_nn, dim3(nb), dim3(TPB), 0, stream, w.noise_list, n_noise, w.cand, sem, w.seg_of_pt,
+        hipLaunchKernelGGL(k_noise_nn, dim3(cdiv((long long)n * 64, TPB)), dim3(TPB), 0, stream, w.noise_list, n_noise, w.cand, sem, w.seg_of_pt,
                            w.seg_off, w.lab2, w.last_assigned, cluster_id, w.fsize);
     }
     int* mstart = member_start ? member_start : w.mstart_tmp;

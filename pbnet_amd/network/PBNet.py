@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from .. import MinkowskiEngine as ME
 from .. import pbnet_ops
+from ..prof import section
 from .Mink import Mink_unet as unet3d
 
 COUNT_MEAN = [-1., -1., 3917., 12056., 2303., 8331., 3948., 3166., 5629., 11719., 1003., 3317., 4912., 10221., 3889.,
@@ -91,8 +92,12 @@ class PBNet(nn.Module):
 
     # ---- PBNet.py:117-136 -------------------------------------------------------------------------------------
     def backbone_stage(self, feat_voxel, xyz_voxel, v2p_v1):
-        inputs_v1 = ME.SparseTensor(feat_voxel, xyz_voxel)
-        point_feat = self.MEUnet(inputs_v1)
+        with section("a3_coords"):
+            inputs_v1 = ME.SparseTensor(feat_voxel, xyz_voxel)
+            inputs_v1.coordinate_manager.level(16)
+        with section("a4_unet"):
+            point_feat = self.MEUnet(inputs_v1)
+        _sec = section("a5_heads_gather"); _sec.__enter__()
         sem_pred_score = self.linear_sem(point_feat)
         sem_pred_score_sf = self.soft_max(sem_pred_score)
         offsets_pred = self.linear_offset(point_feat)
@@ -105,6 +110,7 @@ class PBNet(nn.Module):
             "batch_head_p": xyz_voxel[:, 0][v2p],
         }
         out["sem_pred_p"] = out["sem_pred_score_p"].max(1)[1]
+        _sec.__exit__(None, None, None)
         return out
 
     # ---- PBNet.py:144-279 -------------------------------------------------------------------------------------
@@ -118,6 +124,7 @@ class PBNet(nn.Module):
         n_cls = int(self.sem_num)
 
         # (a6) per-class selection, all classes at once; host learns the [class, batch] population table
+        _sec = section("a6_select"); _sec.__enter__()
         table = torch.bincount(sem_pred_p * nb + batch_head_p, minlength=n_cls * nb)[:n_cls * nb].view(n_cls, nb)
         table_h = table.cpu()                                                     # sync 1
         assert int(table_h.sum()) == sem_pred_p.shape[0], "batch index outside [0, cluster_batch)"  # PBNet.py:286
@@ -135,13 +142,16 @@ class PBNet(nn.Module):
         ins_offseted = ins_orig + offset_pred_p[ins_ind].float()                 # PBNet.py:165 (fp32 add)
         ins_sem = sem_pred_p[ins_ind].to(torch.int32)
         seg_len = table[classes].reshape(-1).to(torch.int32)                      # segments = (class, batch) in order
+        _sec.__exit__(None, None, None)
 
-        res = pbnet_ops.cluster_device(ins_offseted, ins_orig, ins_sem, seg_len, self.radius, self.min_pts)
-        n_clt = int(res.n_clusters.item())                                        # sync 2
+        with section("a7_16_grouping"):
+            res = pbnet_ops.cluster_device(ins_offseted, ins_orig, ins_sem, seg_len, self.radius, self.min_pts)
+            n_clt = int(res.n_clusters.item())                                    # sync 2
         if n_clt < 0:
             raise RuntimeError("grouping rejected its input (class id outside [2,19])")
         if n_clt == 0:
             return self._empty_stage(dev, task)
+        _sec = section("a17_plan"); _sec.__enter__()
         cluster_num = res.cluster_num.cpu().view(len(classes), nb)
         centers = res.centers[:3 * n_clt].cpu().view(n_clt, 3)
         member_start = res.member_start[:n_clt + 1].cpu()
@@ -183,7 +193,9 @@ class PBNet(nn.Module):
         if not scene_len:
             return self._empty_stage(dev, task)
 
+        _sec.__exit__(None, None, None)
         # device gathers over points: rows of every local scene, in the reference's order
+        _sec = section("a17_gather"); _sec.__enter__()
         ent_cluster_t = torch.tensor(ent_cluster, dtype=torch.long)
         ent_rows = sizes[ent_cluster_t]
         ent_scene = torch.repeat_interleave(torch.arange(len(scene_len)), torch.tensor(scene_len))
@@ -200,19 +212,24 @@ class PBNet(nn.Module):
         feat = torch.cat([point_feat_p[point_idx], row_sem_sf.view(-1, 1).to(point_feat_p.dtype),
                           row_weight.view(-1, 1).to(point_feat_p.dtype)], 1)     # [R, 34]  PBNet.py:194,230
         out = {}
+        _sec.__exit__(None, None, None)
 
         # (a18) mask branch
-        coords = torch.cat([row_scene.view(-1, 1).to(torch.int32),
-                            torch.floor(xyz_original[point_idx] / LOCAL_VOXEL).to(torch.int32)], 1)
-        inputs_v2 = ME.SparseTensor(feat, coords)
-        mask_score = self.linear_binary(self.D_Unet(inputs_v2)).F[inputs_v2.inverse_mapping]   # [R, 1]
+        with section("a18_mask_coords"):
+            coords = torch.cat([row_scene.view(-1, 1).to(torch.int32),
+                                torch.floor(xyz_original[point_idx] / LOCAL_VOXEL).to(torch.int32)], 1)
+            inputs_v2 = ME.SparseTensor(feat, coords)
+            inputs_v2.coordinate_manager.level(16)
+        with section("a18_mask_unet"):
+            mask_score = self.linear_binary(self.D_Unet(inputs_v2)).F[inputs_v2.inverse_mapping]   # [R, 1]
         if task != "test":
             gt_rows = d(torch.tensor(scene_gt, dtype=torch.long))[row_scene]
             lab = ins_label[point_idx]
             gt_mask = (lab == gt_rows).long()
             gt_mask[lab == -100] = -1
             out["mask_scores"] = (mask_score, gt_mask.detach())
-        out["proposals"] = self.get_proposal(row_scene, point_idx, mask_score)
+        with section("a19_proposals"):
+            out["proposals"] = self.get_proposal(row_scene, point_idx, mask_score)
 
         # (a20) score branch
         proposals_idx, proposals_offset, _, _ = out["proposals"]
@@ -220,10 +237,18 @@ class PBNet(nn.Module):
             pidx = proposals_idx[:, 1]
             c3 = torch.floor(xyz_original[pidx] * self.scale_size / self.voxel_size).to(torch.int32)
             coords3 = torch.cat([proposals_idx[:, 0:1].to(torch.int32), c3], 1)
-            inputs_v3 = ME.SparseTensor(point_feat_p[pidx], coords3)
-            iou_feat = self.linear_IOU_feat(self.score_Unet(inputs_v3))
-            global_feat = self.global_max_pool(iou_feat) + self.global_avg_pool(iou_feat)
-            out["clt_scores"] = self.linear_IOU(global_feat).F.view(-1)
+            with section("a20_score_coords"):
+                inputs_v3 = ME.SparseTensor(point_feat_p[pidx], coords3)
+                inputs_v3.coordinate_manager.level(16)
+            with section("a20_score_unet"):
+                iou_feat = self.linear_IOU_feat(self.score_Unet(inputs_v3))
+            with section("a20_pool_head"):
+                # global max + avg pooling per proposal (PBNet.py:274-276); rows are grouped by proposal id
+                from ..MinkowskiEngine.nn import segment_pool, _PooledTensor
+                n_prop = int(proposals_offset.shape[0]) - 1
+                mx, av = segment_pool(iou_feat.F, inputs_v3.C[:, 0], n_prop)
+                global_feat = _PooledTensor((mx + av).to(iou_feat.F.dtype))
+                out["clt_scores"] = self.linear_IOU(global_feat).F.view(-1)
         else:
             out["clt_scores"] = torch.zeros(0, dtype=torch.float32, device=dev)
         return out
