@@ -15,6 +15,19 @@ def _i32(n, dev, fill=None):
     return torch.full((n,), fill, dtype=torch.int32, device=dev)
 
 
+_OFFSETS = {}
+
+
+def _device_offsets(kernel_size, stride, device):
+    """Kernel offsets live on the device once per (kernel, stride): no per-forward host->device copy."""
+    key = (int(kernel_size), int(stride), device)
+    t = _OFFSETS.get(key)
+    if t is None:
+        t = CV.kernel_offsets(kernel_size, stride).to(device)
+        _OFFSETS[key] = t
+    return t
+
+
 class _Level(object):
     """One tensor stride of a coordinate pyramid: coordinates, hash table, parent links to the next coarser level."""
     __slots__ = ("stride", "coords", "n", "n_dev", "keys", "vals", "capacity", "parent_row", "child_k", "nbr_down")
@@ -22,7 +35,10 @@ class _Level(object):
 
 class CoordinateManager(object):
     """Owns the coordinate sets of one SparseTensor lineage and the kernel maps between them (ME caches both per
-    lineage in its coordinate manager, so transposed convolutions land exactly on the encoder's coordinates)."""
+    lineage in its coordinate manager, so transposed convolutions land exactly on the encoder's coordinates).
+
+    Construction launches the de-duplication AND the four coarser levels back to back on device-resident row counts;
+    the five counts come back in ONE host read the first time a size is needed."""
 
     MAX_STRIDE = 16
 
@@ -33,100 +49,80 @@ class CoordinateManager(object):
         dev = coords.device
         lib = N.lib()
         n = int(coords.shape[0])
-        cap = lib.pbn_hash_capacity(n)
-        lv = _Level()
-        lv.stride = 1
-        lv.capacity = cap
-        lv.keys = torch.empty(cap, dtype=torch.int64, device=dev)
-        lv.vals = _i32(cap, dev)
-        lv.n_dev = _i32(1, dev)
-        unique_index = _i32(max(n, 1), dev)
-        inverse = _i32(max(n, 1), dev)
-        ucoords = torch.empty(max(n, 1), 4, dtype=torch.int32, device=dev)
-        ws_bytes = lib.pbn_coords_workspace_bytes(n)
-        self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        rc = lib.pbn_coords_unique(N.ptr(coords), None, n, N.ptr(lv.keys), N.ptr(lv.vals), cap, N.ptr(unique_index),
-                                   N.ptr(inverse), N.ptr(ucoords), N.ptr(lv.n_dev), N.ptr(self._ws), ws_bytes,
-                                   N.current_stream())
-        N.check(rc, "pbn_coords_unique")
         self.device = dev
         self.n_input = n
-        self._levels = {1: lv}
-        self._pending = (ucoords, unique_index, inverse)
         self._maps = {}
-        self._built = False
-        lv.coords = ucoords
-        lv.parent_row = lv.child_k = lv.nbr_down = None
-        lv.n = None
-        self.unique_index = None
-        self.inverse_mapping = None
+        self._levels = {}
+        self._counts = torch.empty(5, dtype=torch.int32, device=dev)
+        ws_bytes = lib.pbn_coords_workspace_bytes(n)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        stream = N.current_stream()
+        cap0 = max(n, 1)
 
-    # -- sizes ------------------------------------------------------------------------------------------------
-    def _finalize_level1(self):
-        lv = self._levels[1]
-        if lv.n is None:
-            n = int(lv.n_dev.item())  # one host sync per lineage root
-            if n < 0:
-                raise ValueError("coordinate out of range: batch must be in [0,65534], x/y/z in [-32768,32767]")
-            ucoords, unique_index, inverse = self._pending
-            lv.n = n
-            lv.coords = ucoords[:n]
-            self.unique_index = unique_index[:n].long()
-            self.inverse_mapping = inverse[:self.n_input].long()
-            self.is_identity = (n == self.n_input)
-            self._pending = None
-        return lv
-
-    def _build_pyramid(self):
-        """All coarser levels back to back on device counts, then ONE host read of the four row counts."""
-        if self._built:
-            return
-        lib = N.lib()
-        fine = self._finalize_level1()
-        dev = self.device
-        made = []
-        s = 2
-        while s <= self.MAX_STRIDE:
-            nf = fine.n if fine.n is not None else fine.coords.shape[0]
+        def new_level(stride, idx):
             lv = _Level()
-            lv.stride = s
-            lv.capacity = lib.pbn_hash_capacity(nf)
+            lv.stride = stride
+            lv.capacity = lib.pbn_hash_capacity(n)
             lv.keys = torch.empty(lv.capacity, dtype=torch.int64, device=dev)
             lv.vals = _i32(lv.capacity, dev)
-            lv.n_dev = _i32(1, dev)
-            lv.coords = torch.empty(max(nf, 1), 4, dtype=torch.int32, device=dev)
+            lv.n_dev = self._counts[idx:idx + 1]
+            lv.coords = torch.empty(cap0, 4, dtype=torch.int32, device=dev)
             lv.n = None
             lv.parent_row = lv.child_k = lv.nbr_down = None
-            fine.parent_row = _i32(max(nf, 1), dev)
-            fine.child_k = _i32(max(nf, 1), dev)
-            fine.nbr_down = torch.empty(max(nf, 1), 8, dtype=torch.int32, device=dev)
-            ws_bytes = lib.pbn_coords_workspace_bytes(nf)
-            if self._ws.numel() < ws_bytes:
-                self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            rc = lib.pbn_coords_stride(N.ptr(fine.coords), N.ptr(fine.n_dev) if fine.n is None else None, nf, s,
-                                       N.ptr(lv.keys), N.ptr(lv.vals), lv.capacity, N.ptr(lv.coords),
-                                       N.ptr(fine.parent_row), N.ptr(fine.child_k), N.ptr(fine.nbr_down),
-                                       N.ptr(lv.n_dev), N.ptr(self._ws), self._ws.numel(), N.current_stream())
+            self._levels[stride] = lv
+            return lv
+
+        lv = new_level(1, 0)
+        self._unique_index = _i32(cap0, dev)
+        self._inverse = _i32(cap0, dev)
+        rc = lib.pbn_coords_unique(N.ptr(coords), None, n, N.ptr(lv.keys), N.ptr(lv.vals), lv.capacity,
+                                   N.ptr(self._unique_index), N.ptr(self._inverse), N.ptr(lv.coords), N.ptr(lv.n_dev),
+                                   N.ptr(ws), ws_bytes, stream)
+        N.check(rc, "pbn_coords_unique")
+        fine, s, idx = lv, 2, 1
+        while s <= self.MAX_STRIDE:
+            lv = new_level(s, idx)
+            fine.parent_row = _i32(cap0, dev)
+            fine.child_k = _i32(cap0, dev)
+            fine.nbr_down = torch.empty(cap0, 8, dtype=torch.int32, device=dev)
+            rc = lib.pbn_coords_stride(N.ptr(fine.coords), N.ptr(fine.n_dev), n, s, N.ptr(lv.keys), N.ptr(lv.vals),
+                                       lv.capacity, N.ptr(lv.coords), N.ptr(fine.parent_row), N.ptr(fine.child_k),
+                                       N.ptr(fine.nbr_down), N.ptr(lv.n_dev), N.ptr(ws), ws_bytes, stream)
             N.check(rc, "pbn_coords_stride")
-            self._levels[s] = lv
-            made.append(lv)
-            fine = lv
-            s *= 2
-        counts = torch.cat([lv.n_dev for lv in made]).tolist()  # single sync
-        prev = self._levels[1]
-        for lv, n in zip(made, counts):
-            lv.n = int(n)
+            fine, s, idx = lv, s * 2, idx + 1
+        self._ws = ws
+        self._final = False
+        self.unique_index = None
+        self.inverse_mapping = None
+        self.is_identity = None
+
+    # -- sizes ------------------------------------------------------------------------------------------------
+    def _finalize(self):
+        if self._final:
+            return
+        counts = self._counts.tolist()  # the one host synchronisation of this lineage
+        if counts[0] < 0:
+            raise ValueError("coordinate out of range: batch must be in [0,65534], x/y/z in [-32768,32767]")
+        prev = None
+        for lv, c in zip((self._levels[s] for s in (1, 2, 4, 8, 16)), counts):
+            lv.n = int(c)
             lv.coords = lv.coords[:lv.n]
-            prev.parent_row = prev.parent_row[:prev.n]
-            prev.child_k = prev.child_k[:prev.n]
-            prev.nbr_down = prev.nbr_down[:lv.n]
+            if prev is not None:
+                prev.parent_row = prev.parent_row[:prev.n]
+                prev.child_k = prev.child_k[:prev.n]
+                prev.nbr_down = prev.nbr_down[:lv.n]
             prev = lv
-        self._built = True
+        n1 = self._levels[1].n
+        self.unique_index = self._unique_index[:n1].long()
+        self.inverse_mapping = self._inverse[:self.n_input].long()
+        self.is_identity = (n1 == self.n_input)
+        self._final = True
+
+    def _build_pyramid(self):
+        self._finalize()
 
     def level(self, stride):
-        if stride == 1:
-            return self._finalize_level1()
-        self._build_pyramid()
+        self._finalize()
         return self._levels[stride]
 
     def num_rows(self, stride):
@@ -141,7 +137,7 @@ class CoordinateManager(object):
         key = ("k", stride, kernel_size)
         if key not in self._maps:
             lv = self.level(stride)
-            off = CV.kernel_offsets(kernel_size, stride).to(self.device)
+            off = _device_offsets(kernel_size, stride, self.device)
             k = int(off.shape[0])
             nbr = torch.empty(max(lv.n, 1), k, dtype=torch.int32, device=self.device)
             rc = N.lib().pbn_kernel_map(N.ptr(lv.coords), None, lv.n, N.ptr(off), k, N.ptr(lv.keys), N.ptr(lv.vals),

@@ -146,15 +146,17 @@ class PBNet(nn.Module):
 
         with section("a7_16_grouping"):
             res = pbnet_ops.cluster_device(ins_offseted, ins_orig, ins_sem, seg_len, self.radius, self.min_pts)
-            n_clt = int(res.n_clusters.item())                                    # sync 2
+            head = torch.cat([res.n_clusters, res.cluster_num]).cpu()                # sync 2
+            n_clt = int(head[0])
         if n_clt < 0:
             raise RuntimeError("grouping rejected its input (class id outside [2,19])")
         if n_clt == 0:
             return self._empty_stage(dev, task)
         _sec = section("a17_plan"); _sec.__enter__()
-        cluster_num = res.cluster_num.cpu().view(len(classes), nb)
-        centers = res.centers[:3 * n_clt].cpu().view(n_clt, 3)
-        member_start = res.member_start[:n_clt + 1].cpu()
+        cluster_num = head[1:].view(len(classes), nb)
+        packed = torch.cat([res.centers[:3 * n_clt], res.member_start[:n_clt + 1].view(torch.float32)]).cpu()  # sync 3
+        centers = packed[:3 * n_clt].view(n_clt, 3)
+        member_start = packed[3 * n_clt:].view(torch.int32)
         sizes = (member_start[1:] - member_start[:-1])
         labels_h = None
         if task != "test":
@@ -229,7 +231,7 @@ class PBNet(nn.Module):
             gt_mask[lab == -100] = -1
             out["mask_scores"] = (mask_score, gt_mask.detach())
         with section("a19_proposals"):
-            out["proposals"] = self.get_proposal(row_scene, point_idx, mask_score)
+            out["proposals"] = self.get_proposal(row_scene, point_idx, mask_score, n_scenes=len(scene_len))
 
         # (a20) score branch
         proposals_idx, proposals_offset, _, _ = out["proposals"]
@@ -263,17 +265,27 @@ class PBNet(nn.Module):
         return out
 
     # ---- PBNet.py:317-347 as one device compaction ----------------------------------------------------------------
-    def get_proposal(self, row_scene, point_idx, mask_score, mask_score_thd=MASK_THD):
+    def get_proposal(self, row_scene, point_idx, mask_score, mask_score_thd=MASK_THD, n_scenes=None):
+        """row_scene i64[R] (local-scene id per row, ascending), point_idx i64[R], mask_score [R,1].
+        One host read (rows kept per local scene); everything else stays on the device."""
         assert row_scene.shape[0] == mask_score.shape[0]
-        valid = torch.nonzero(mask_score.view(-1).float() > mask_score_thd).view(-1)
-        scene = row_scene[valid]
+        dev = row_scene.device
+        if n_scenes is None:
+            n_scenes = int(row_scene.max().item()) + 1 if row_scene.numel() else 0
+        keep = mask_score.view(-1).float() > mask_score_thd
+        per_scene = torch.bincount(row_scene[keep], minlength=n_scenes).cpu()       # sync
+        total = int(per_scene.sum())
+        valid = torch.nonzero_static(keep, size=total).view(-1)
         proposals_ms = mask_score[valid].view(-1)
-        cluster_id_v, dense, cluster_len = torch.unique(scene, return_inverse=True, return_counts=True)
-        proposals_offset = torch.zeros(cluster_len.shape[0] + 1, dtype=torch.int64, device=scene.device)
-        proposals_offset[1:] = torch.cumsum(cluster_len, 0)
+        alive = per_scene > 0
+        cluster_id_v = torch.nonzero(alive).view(-1)                                # surviving scene ids (host)
+        proposals_offset = torch.zeros(int(alive.sum()) + 1, dtype=torch.int64)
+        proposals_offset[1:] = torch.cumsum(per_scene[alive], 0)
         # "remove null proposals" (PBNet.py:342-345) == dense renumbering of the surviving local scenes
-        proposals_idx = torch.stack([dense.view(-1), point_idx[valid]], 1).to(torch.int64)
-        return proposals_idx.detach(), proposals_offset.detach(), cluster_id_v.detach(), proposals_ms
+        dense_of = torch.cumsum(alive.to(torch.int64), 0) - 1
+        dense = dense_of.to(dev)[row_scene[valid]]
+        proposals_idx = torch.stack([dense, point_idx[valid]], 1).to(torch.int64)
+        return proposals_idx.detach(), proposals_offset.to(dev), cluster_id_v.to(dev), proposals_ms
 
 
 def model_fn(batch, model, epoch, cfg, task="train"):

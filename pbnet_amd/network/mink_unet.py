@@ -17,6 +17,7 @@ import torch.nn as nn
 from .. import MinkowskiEngine as ME
 from ..MinkowskiEngine.conv import spconv_forward, _pad_vec
 from ..MinkowskiEngine.modules.resnet_block import BasicBlock
+from ..prof import section
 
 # arch -> (blocks per stage, planes)   (Mink.py:357-419; BasicBlock families only)
 SPECS = {
@@ -144,8 +145,11 @@ class MinkUNet(nn.Module):
         assert x.tensor_stride == 1
         P = self.PLANES
         dt, dev = x.F.dtype, x.F.device
-        n = {s: cm.num_rows(s) for s in (1, 2, 4, 8, 16)}
-        k3 = {s: cm.kernel_map(s, 3) for s in (1, 2, 4, 8, 16)}
+        with section("unet.maps"):
+            n = {s: cm.num_rows(s) for s in (1, 2, 4, 8, 16)}
+            k3 = {s: cm.kernel_map(s, 3) for s in (1, 2, 4, 8, 16)}
+            k5 = cm.kernel_map(1, 5)
+            ups = {s: cm.up_map(s) for s in (2, 4, 8, 16)}
         skip_c = (INIT_DIM, P[0], P[1], P[2])                      # channels of out_p1, out_b1p2, out_b2p4, out_b3p8
         up_c = (P[7], P[6], P[5], P[4])                            # transposed-conv channels landing at stride 1,2,4,8
         strides = (1, 2, 4, 8)
@@ -154,17 +158,22 @@ class MinkUNet(nn.Module):
         skip_view = {s: slab[s][:, up_c[i]:] for i, s in enumerate(strides)}
         up_view = {s: slab[s][:, :up_c[i]] for i, s in enumerate(strides)}
 
-        cur = self._cbr(self.conv0p1s1, self.bn0, x.F, cm.kernel_map(1, 5), n[1], out=skip_view[1])
+        with section("unet.stem"):
+            cur = self._cbr(self.conv0p1s1, self.bn0, x.F, k5, n[1], out=skip_view[1])
         s = 1
+        _sec = section("unet.encoder"); _sec.__enter__()
         for i in range(4):
             cur = self._cbr(getattr(self, _DOWN[i]), getattr(self, _DOWN_BN[i]), cur, cm.down_map(s), n[2 * s])
             s *= 2
             cur = self._stage_fused(getattr(self, "block%d" % (i + 1)), cur, k3[s], n[s],
                                     out=skip_view[s] if s < 16 else None)
+        _sec.__exit__(None, None, None)
+        _sec = section("unet.decoder"); _sec.__enter__()
         for i in range(4):
-            self._cbr(getattr(self, _UP[i]), getattr(self, _UP_BN[i]), cur, cm.up_map(s), n[s // 2], out=up_view[s // 2])
+            self._cbr(getattr(self, _UP[i]), getattr(self, _UP_BN[i]), cur, ups[s], n[s // 2], out=up_view[s // 2])
             s //= 2
             cur = self._stage_fused(getattr(self, "block%d" % (i + 5)), slab[s], k3[s], n[s])
+        _sec.__exit__(None, None, None)
         fs = self.final_sematic
         packed = fs._cache.get(fs.kernel, dt)
         out = spconv_forward(cur, None, n[1], packed, shift=_pad_vec(fs.bias, packed[3], 0.0))
