@@ -124,6 +124,12 @@ int pbn_kernel_map(const int32_t* out_coords, const int32_t* n_out_dev, int n_ou
                    int n_offsets, const uint64_t* table_keys, const int32_t* table_vals, int capacity, int32_t* nbr,
                    pbn_stream_t stream);
 
+/* Kernel map of a K^3 hyper-cube whose offsets are generated on the fly: odd K centred, even K not, offsets scaled by
+ * tensor_stride, first spatial dimension fastest when x_fastest != 0 (the MinkowskiEngine convention assumed here). */
+int pbn_kernel_map_cube(const int32_t* out_coords, const int32_t* n_out_dev, int n_out_max, int kernel_size,
+                        int tensor_stride, int x_fastest, const uint64_t* table_keys, const int32_t* table_vals,
+                        int capacity, int32_t* nbr, pbn_stream_t stream);
+
 /* Table of the transposed k=2,s=2 convolution: nbr_up[fine_row, k] = parent row for k == child_k[fine_row], else -1. */
 int pbn_up_table(const int32_t* parent_row, const int32_t* child_k, const int32_t* n_fine_dev, int n_fine_max,
                  int32_t* nbr_up, pbn_stream_t stream);
@@ -164,6 +170,51 @@ int pbn_gather_rows(const void* in, int ld_in_bytes, const int64_t* idx, int n, 
  * An empty segment yields -inf / NaN exactly like the reductions it replaces.  Deterministic. */
 int pbn_segment_pool(const void* feats, int ld, int channels, int dtype, const int32_t* seg_start, int n_seg,
                      float* out_max, float* out_avg, pbn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * One-call sub-pipelines (csrc/executor.hip): they only sequence the entry points above.
+ *
+ * pbn_coords_build: everything a MinkUNet needs from one coordinate lineage -- de-duplication, the four coarser
+ * levels (tensor strides 2..16), the k=3 maps of all five levels, optionally the k=5 map of level 0, and the four
+ * transposed-convolution tables -- laid out in one caller-owned arena.  Every array is sized for n rows (the input
+ * size bounds every level); the real row counts are the first five ints at `counts` (device memory, -1 = range error).
+ * Layout offsets are bytes from the arena base and are filled by pbn_coords_arena_bytes(). */
+typedef struct {
+    int64_t counts, unique_index, inverse;
+    int64_t keys[5], vals[5], coords[5], k3[5];
+    int64_t parent_row[4], child_k[4], nbr_down[4], up[4];
+    int64_t k5, workspace, workspace_bytes;
+    int32_t capacity[5];
+    int32_t _pad;
+} pbn_coords_layout;
+
+size_t pbn_coords_arena_bytes(int n, int want_k5, pbn_coords_layout* layout);
+int pbn_coords_build(const int32_t* coords, int n, int want_k5, int x_fastest, void* arena, size_t arena_bytes,
+                     const pbn_coords_layout* layout, pbn_stream_t stream);
+
+/* pbn_unet_forward: executes a static list of fused convolutions -- MinkUNetBase.forward (network/Mink.py:291-354) with
+ * eval-mode BatchNorm, ReLU and residual adds folded into the epilogues and skip concatenations written in place.
+ * Buffers are symbolic: buffer 0 is the caller's input slab, buffer b > 0 is [n_rows[level], width] elements inside the
+ * arena (offsets from pbn_unet_arena_bytes).  map_kind: 0 identity (1x1 / linear), 1 k=3 at level_out, 2 k=5 (level 0),
+ * 3 k=2,s=2 down (level_in = fine level), 4 transposed k=2,s=2 (level_out = fine level). */
+typedef struct {
+    int32_t map_kind, level_in, level_out;
+    int32_t in_buf, in_col, res_buf, res_col, out_buf, out_col;
+    int32_t vpo, n_steps, cout_p, relu, _pad;
+    const void* w;
+    const float* scale;
+    const float* shift;
+} pbn_unet_op;
+
+typedef struct {
+    int32_t level, width;
+} pbn_unet_buf;
+
+size_t pbn_unet_arena_bytes(const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows, int dtype, int64_t* buf_offsets);
+int pbn_unet_forward(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows,
+                     const void* input, int ld_input, const int32_t* const* k3, const int32_t* k5,
+                     const int32_t* const* down, const int32_t* const* up, void* arena, size_t arena_bytes, int dtype,
+                     void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream);
 
 #ifdef __cplusplus
 }

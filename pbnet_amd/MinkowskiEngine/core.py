@@ -3,6 +3,8 @@ touches (/root/reference/network/PBNet.py:117,125-128,240-250,265-271; network/M
 libpbnet_hip.so (csrc/coords.hip).  MinkowskiEngine itself is an un-vendored, un-pinned third-party dependency of
 the reference (README.md:15-27); the behavioural conventions assumed here are listed in conventions.py.
 """
+import ctypes
+
 import torch
 
 from .. import _native as N
@@ -37,12 +39,14 @@ class CoordinateManager(object):
     """Owns the coordinate sets of one SparseTensor lineage and the kernel maps between them (ME caches both per
     lineage in its coordinate manager, so transposed convolutions land exactly on the encoder's coordinates).
 
-    Construction launches the de-duplication AND the four coarser levels back to back on device-resident row counts;
-    the five counts come back in ONE host read the first time a size is needed."""
+    Construction is ONE native call (pbn_coords_build): de-duplication, the four coarser levels, the k=3 maps of all
+    levels, the k=5 map of level 1 and the transposed-convolution tables, laid out in one arena with device-resident
+    row counts.  The five counts come back in ONE host read the first time a size is needed."""
 
     MAX_STRIDE = 16
+    _STRIDES = (1, 2, 4, 8, 16)
 
-    def __init__(self, coordinates):
+    def __init__(self, coordinates, build_maps=True):
         N.require_cuda(coordinates)
         coords = coordinates.to(torch.int32).contiguous()
         assert coords.dim() == 2 and coords.shape[1] == 4, "coordinates must be [N,4] (batch, x, y, z)"
@@ -51,50 +55,40 @@ class CoordinateManager(object):
         n = int(coords.shape[0])
         self.device = dev
         self.n_input = n
+        self.build_maps = build_maps
         self._maps = {}
-        self._levels = {}
-        self._counts = torch.empty(5, dtype=torch.int32, device=dev)
-        ws_bytes = lib.pbn_coords_workspace_bytes(n)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        stream = N.current_stream()
-        cap0 = max(n, 1)
-
-        def new_level(stride, idx):
-            lv = _Level()
-            lv.stride = stride
-            lv.capacity = lib.pbn_hash_capacity(n)
-            lv.keys = torch.empty(lv.capacity, dtype=torch.int64, device=dev)
-            lv.vals = _i32(lv.capacity, dev)
-            lv.n_dev = self._counts[idx:idx + 1]
-            lv.coords = torch.empty(cap0, 4, dtype=torch.int32, device=dev)
-            lv.n = None
-            lv.parent_row = lv.child_k = lv.nbr_down = None
-            self._levels[stride] = lv
-            return lv
-
-        lv = new_level(1, 0)
-        self._unique_index = _i32(cap0, dev)
-        self._inverse = _i32(cap0, dev)
-        rc = lib.pbn_coords_unique(N.ptr(coords), None, n, N.ptr(lv.keys), N.ptr(lv.vals), lv.capacity,
-                                   N.ptr(self._unique_index), N.ptr(self._inverse), N.ptr(lv.coords), N.ptr(lv.n_dev),
-                                   N.ptr(ws), ws_bytes, stream)
-        N.check(rc, "pbn_coords_unique")
-        fine, s, idx = lv, 2, 1
-        while s <= self.MAX_STRIDE:
-            lv = new_level(s, idx)
-            fine.parent_row = _i32(cap0, dev)
-            fine.child_k = _i32(cap0, dev)
-            fine.nbr_down = torch.empty(cap0, 8, dtype=torch.int32, device=dev)
-            rc = lib.pbn_coords_stride(N.ptr(fine.coords), N.ptr(fine.n_dev), n, s, N.ptr(lv.keys), N.ptr(lv.vals),
-                                       lv.capacity, N.ptr(lv.coords), N.ptr(fine.parent_row), N.ptr(fine.child_k),
-                                       N.ptr(fine.nbr_down), N.ptr(lv.n_dev), N.ptr(ws), ws_bytes, stream)
-            N.check(rc, "pbn_coords_stride")
-            fine, s, idx = lv, s * 2, idx + 1
-        self._ws = ws
         self._final = False
-        self.unique_index = None
-        self.inverse_mapping = None
-        self.is_identity = None
+        self.unique_index = self.inverse_mapping = self.is_identity = None
+        self._n = None
+        if build_maps:
+            self._layout = N.CoordsLayout()
+            nbytes = lib.pbn_coords_arena_bytes(n, 1, ctypes.byref(self._layout))
+            self._arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            rc = lib.pbn_coords_build(N.ptr(coords), n, 1, int(CV.X_FASTEST), N.ptr(self._arena), nbytes,
+                                      ctypes.byref(self._layout), N.current_stream())
+            N.check(rc, "pbn_coords_build")
+            self._counts = self._view(self._layout.counts, 5, torch.int32)
+        else:  # de-duplication only (ME.utils.sparse_quantize)
+            cap = lib.pbn_hash_capacity(n)
+            self._keys = torch.empty(cap, dtype=torch.int64, device=dev)
+            self._vals = _i32(cap, dev)
+            self._counts = _i32(1, dev)
+            self._uidx, self._inv = _i32(max(n, 1), dev), _i32(max(n, 1), dev)
+            self._ucoords = torch.empty(max(n, 1), 4, dtype=torch.int32, device=dev)
+            wsb = lib.pbn_coords_workspace_bytes(n)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            rc = lib.pbn_coords_unique(N.ptr(coords), None, n, N.ptr(self._keys), N.ptr(self._vals), cap,
+                                       N.ptr(self._uidx), N.ptr(self._inv), N.ptr(self._ucoords), N.ptr(self._counts),
+                                       N.ptr(ws), wsb, N.current_stream())
+            N.check(rc, "pbn_coords_unique")
+
+    def _view(self, offset, count, dtype, shape=None):
+        nbytes = count * torch.empty(0, dtype=dtype).element_size()
+        t = self._arena[offset:offset + nbytes].view(dtype)
+        return t if shape is None else t.view(shape)
+
+    def _ptr(self, offset):
+        return self._arena.data_ptr() + offset
 
     # -- sizes ------------------------------------------------------------------------------------------------
     def _finalize(self):
@@ -103,66 +97,75 @@ class CoordinateManager(object):
         counts = self._counts.tolist()  # the one host synchronisation of this lineage
         if counts[0] < 0:
             raise ValueError("coordinate out of range: batch must be in [0,65534], x/y/z in [-32768,32767]")
-        prev = None
-        for lv, c in zip((self._levels[s] for s in (1, 2, 4, 8, 16)), counts):
-            lv.n = int(c)
-            lv.coords = lv.coords[:lv.n]
-            if prev is not None:
-                prev.parent_row = prev.parent_row[:prev.n]
-                prev.child_k = prev.child_k[:prev.n]
-                prev.nbr_down = prev.nbr_down[:lv.n]
-            prev = lv
-        n1 = self._levels[1].n
-        self.unique_index = self._unique_index[:n1].long()
-        self.inverse_mapping = self._inverse[:self.n_input].long()
+        self._n = [int(c) for c in counts]
+        n1 = self._n[0]
+        if self.build_maps:
+            self.unique_index = self._view(self._layout.unique_index, n1, torch.int32).long()
+            self.inverse_mapping = self._view(self._layout.inverse, self.n_input, torch.int32).long()
+        else:
+            self.unique_index = self._uidx[:n1].long()
+            self.inverse_mapping = self._inv[:self.n_input].long()
         self.is_identity = (n1 == self.n_input)
         self._final = True
 
-    def _build_pyramid(self):
-        self._finalize()
-
-    def level(self, stride):
-        self._finalize()
-        return self._levels[stride]
+    def _level_index(self, stride):
+        assert self.build_maps, "this coordinate manager was built for de-duplication only"
+        return self._STRIDES.index(stride)
 
     def num_rows(self, stride):
-        return self.level(stride).n
+        self._finalize()
+        return self._n[self._STRIDES.index(stride)] if self.build_maps else self._n[0]
+
+    def row_counts(self):
+        self._finalize()
+        return list(self._n)
 
     def coordinates(self, stride):
-        return self.level(stride).coords
+        self._finalize()
+        if not self.build_maps:
+            return self._ucoords[:self._n[0]]
+        l = self._level_index(stride)
+        return self._view(self._layout.coords[l], self._n[l] * 4, torch.int32, (self._n[l], 4))
 
-    # -- kernel maps ------------------------------------------------------------------------------------------
+    # -- kernel maps (views into the arena; rows beyond the level's count are never touched) ---------------------
     def kernel_map(self, stride, kernel_size):
         """nbr[n(stride), K^3] for a stride-1 (in the tensor-stride sense) convolution of odd kernel size."""
+        self._finalize()
+        l = self._level_index(stride)
+        if kernel_size == 3:
+            return self._view(self._layout.k3[l], self._n[l] * 27, torch.int32, (self._n[l], 27))
+        if kernel_size == 5 and stride == 1:
+            return self._view(self._layout.k5, self._n[0] * 125, torch.int32, (self._n[0], 125))
         key = ("k", stride, kernel_size)
         if key not in self._maps:
-            lv = self.level(stride)
-            off = _device_offsets(kernel_size, stride, self.device)
-            k = int(off.shape[0])
-            nbr = torch.empty(max(lv.n, 1), k, dtype=torch.int32, device=self.device)
-            rc = N.lib().pbn_kernel_map(N.ptr(lv.coords), None, lv.n, N.ptr(off), k, N.ptr(lv.keys), N.ptr(lv.vals),
-                                        lv.capacity, N.ptr(nbr), N.current_stream())
-            N.check(rc, "pbn_kernel_map")
-            self._maps[key] = nbr[:lv.n]
+            n = self._n[l]
+            nbr = torch.empty(max(n, 1), kernel_size ** 3, dtype=torch.int32, device=self.device)
+            rc = N.lib().pbn_kernel_map_cube(N.c_vp(self._ptr(self._layout.coords[l])), None, n, kernel_size, stride,
+                                             int(CV.X_FASTEST), N.c_vp(self._ptr(self._layout.keys[l])),
+                                             N.c_vp(self._ptr(self._layout.vals[l])), self._layout.capacity[l],
+                                             N.ptr(nbr), N.current_stream())
+            N.check(rc, "pbn_kernel_map_cube")
+            self._maps[key] = nbr[:n]
         return self._maps[key]
 
     def down_map(self, stride_in):
         """k=2,s=2 convolution stride_in -> 2*stride_in: nbr_down[n_coarse, 8] child rows."""
-        self._build_pyramid()
-        return self._levels[stride_in].nbr_down
+        self._finalize()
+        l = self._level_index(stride_in)
+        return self._view(self._layout.nbr_down[l], self._n[l + 1] * 8, torch.int32, (self._n[l + 1], 8))
 
     def up_map(self, stride_in):
         """Transposed k=2,s=2 convolution stride_in -> stride_in/2: nbr_up[n_fine, 8]."""
-        key = ("u", stride_in)
-        if key not in self._maps:
-            self._build_pyramid()
-            fine = self._levels[stride_in // 2]
-            nbr = torch.empty(max(fine.n, 1), 8, dtype=torch.int32, device=self.device)
-            rc = N.lib().pbn_up_table(N.ptr(fine.parent_row), N.ptr(fine.child_k), None, fine.n, N.ptr(nbr),
-                                      N.current_stream())
-            N.check(rc, "pbn_up_table")
-            self._maps[key] = nbr[:fine.n]
-        return self._maps[key]
+        self._finalize()
+        l = self._level_index(stride_in) - 1
+        return self._view(self._layout.up[l], self._n[l] * 8, torch.int32, (self._n[l], 8))
+
+    def native_tables(self):
+        """Raw device addresses for the native U-Net executor: (k3[5], k5, down[4], up[4])."""
+        self._finalize()
+        L = self._layout
+        return ([self._ptr(L.k3[l]) for l in range(5)], self._ptr(L.k5), [self._ptr(L.nbr_down[l]) for l in range(4)],
+                [self._ptr(L.up[l]) for l in range(4)])
 
 
 class SparseTensor(object):
@@ -183,7 +186,7 @@ class SparseTensor(object):
             assert coordinates is not None
             N.require_cuda(features, coordinates)
             cm = CoordinateManager(coordinates)
-            cm.level(1)
+            cm.num_rows(1)
             if not cm.is_identity:
                 features = features[cm.unique_index]
             coordinate_manager = cm

@@ -18,6 +18,32 @@ c_int = ctypes.c_int
 c_float = ctypes.c_float
 c_size = ctypes.c_size_t
 
+c_i64 = ctypes.c_int64
+c_i32 = ctypes.c_int32
+
+
+class CoordsLayout(ctypes.Structure):
+    """pbn_coords_layout (include/pbnet_hip.h)."""
+    _fields_ = [("counts", c_i64), ("unique_index", c_i64), ("inverse", c_i64),
+                ("keys", c_i64 * 5), ("vals", c_i64 * 5), ("coords", c_i64 * 5), ("k3", c_i64 * 5),
+                ("parent_row", c_i64 * 4), ("child_k", c_i64 * 4), ("nbr_down", c_i64 * 4), ("up", c_i64 * 4),
+                ("k5", c_i64), ("workspace", c_i64), ("workspace_bytes", c_i64),
+                ("capacity", c_i32 * 5), ("_pad", c_i32)]
+
+
+class UnetOp(ctypes.Structure):
+    """pbn_unet_op (include/pbnet_hip.h)."""
+    _fields_ = [("map_kind", c_i32), ("level_in", c_i32), ("level_out", c_i32),
+                ("in_buf", c_i32), ("in_col", c_i32), ("res_buf", c_i32), ("res_col", c_i32), ("out_buf", c_i32),
+                ("out_col", c_i32), ("vpo", c_i32), ("n_steps", c_i32), ("cout_p", c_i32), ("relu", c_i32),
+                ("_pad", c_i32), ("w", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p)]
+
+
+class UnetBuf(ctypes.Structure):
+    """pbn_unet_buf (include/pbnet_hip.h)."""
+    _fields_ = [("level", c_i32), ("width", c_i32)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/pbnet_hip.h (tests/test_abi.py checks this)
 SIGNATURES = {
     "pbn_version": (ctypes.c_char_p, []),
@@ -40,6 +66,14 @@ SIGNATURES = {
                                    c_f32p, c_f32p, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "pbn_gather_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "pbn_segment_pool": (c_int, [c_vp, c_int, c_int, c_int, c_i32p, c_int, c_f32p, c_f32p, c_vp]),
+    "pbn_kernel_map_cube": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
+    "pbn_coords_arena_bytes": (c_size, [c_int, c_int, ctypes.POINTER(CoordsLayout)]),
+    "pbn_coords_build": (c_int, [c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(CoordsLayout), c_vp]),
+    "pbn_unet_arena_bytes": (c_size, [ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32), c_int,
+                                      ctypes.POINTER(c_i64)]),
+    "pbn_unet_forward": (c_int, [ctypes.POINTER(UnetOp), c_int, ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32),
+                                 c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp, ctypes.POINTER(ctypes.c_void_p),
+                                 ctypes.POINTER(ctypes.c_void_p), c_vp, c_size, c_int, c_vp, c_size, c_vp]),
 }
 
 ERRORS = {-1: "PBN_ERR_ARG", -2: "PBN_ERR_WORKSPACE", -3: "PBN_ERR_HIP", -4: "PBN_ERR_RANGE", -5: "PBN_ERR_UNSUPPORTED"}
@@ -87,7 +121,7 @@ def ptr(t):
 
 def current_stream():
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def require_cuda(*tensors):

@@ -301,3 +301,43 @@ extern "C" int pbn_up_table(const int32_t* parent_row, const int32_t* child_k, c
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
+
+// ---- kernel map of a K^3 hyper-cube generated on the fly (no offsets array): ME conventions C1/C2 ---------------------
+namespace pbn {
+namespace {
+__global__ __launch_bounds__(TPB) void k_kernel_map_cube(const int* __restrict__ out_coords, const int* n_dev, int n_max,
+                                                        int ksize, int stride, int x_fastest,
+                                                        const unsigned long long* __restrict__ keys,
+                                                        const int* __restrict__ vals, unsigned mask, int* __restrict__ nbr) {
+    const int K = ksize * ksize * ksize;
+    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+    const int n = real_n(n_dev, n_max);
+    if (e >= (long long)n * K) return;
+    const int row = (int)(e / K), k = (int)(e % K);
+    const int c0 = (ksize & 1) ? ksize / 2 : 0;  // odd kernels are centred, even ones are not
+    int a = k % ksize - c0, b = (k / ksize) % ksize - c0, c = k / (ksize * ksize) - c0;
+    const int dx = (x_fastest ? a : c) * stride, dy = b * stride, dz = (x_fastest ? c : a) * stride;
+    const int4 cc = reinterpret_cast<const int4*>(out_coords)[row];
+    const int x = cc.y + dx, y = cc.z + dy, z = cc.w + dz;
+    int r = -1;
+    if (in_range(cc.x, x, y, z)) r = table_find(keys, vals, mask, pack4(cc.x, x, y, z));
+    nbr[e] = r;
+}
+}  // namespace
+}  // namespace pbn
+
+extern "C" int pbn_kernel_map_cube(const int32_t* out_coords, const int32_t* n_out_dev, int n_out_max, int kernel_size,
+                                   int tensor_stride, int x_fastest, const uint64_t* table_keys,
+                                   const int32_t* table_vals, int capacity, int32_t* nbr, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_out_max < 0 || kernel_size < 1 || tensor_stride < 1 || capacity < 1024 || (capacity & (capacity - 1)))
+        return PBN_ERR_ARG;
+    if (n_out_max == 0) return PBN_OK;
+    if (!out_coords || !table_keys || !table_vals || !nbr) return PBN_ERR_ARG;
+    const long long total = (long long)n_out_max * kernel_size * kernel_size * kernel_size;
+    hipLaunchKernelGGL(k_kernel_map_cube, dim3(cdiv(total, TPB)), dim3(TPB), 0, stream, out_coords, n_out_dev, n_out_max,
+                       kernel_size, tensor_stride, x_fastest, (const unsigned long long*)table_keys, table_vals,
+                       (unsigned)capacity - 1, nbr);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}

@@ -1,0 +1,130 @@
+// executor.hip -- whole sub-pipelines behind ONE C call each, so the host issues a coordinate pyramid or a fused
+// U-Net forward in microseconds instead of hundreds of interpreter round trips:
+//   pbn_coords_build  : de-duplication + 4 strided levels + every kernel map a MinkUNet needs (k=5 @1, k=3 @1..16,
+//                       up tables @2..16) into one caller-owned arena; row counts stay on the device.
+//   pbn_unet_forward  : executes a static plan (list of fused convolution ops over symbolic buffers) -- the body of
+//                       MinkUNetBase.forward (/root/reference/network/Mink.py:291-354) with BatchNorm(eval)/ReLU/residual
+//                       folded into the convolution epilogues and skip concatenations written in place.
+// Both only sequence the kernels of coords.hip / spconv.hip; no new arithmetic lives here.
+#include "pbn_common.h"
+
+using namespace pbn;
+
+static inline size_t a256(size_t x) { return align_up(x, 256); }
+
+extern "C" size_t pbn_coords_arena_bytes(int n, int want_k5, pbn_coords_layout* L) {
+    if (n < 0 || !L) return 0;
+    const size_t N = (size_t)(n > 0 ? n : 1);
+    const int cap = pbn_hash_capacity(n);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = a256(off + bytes); return (int64_t)o; };
+    L->counts = take(8 * sizeof(int));
+    L->unique_index = take(N * 4);
+    L->inverse = take(N * 4);
+    for (int l = 0; l < 5; ++l) {
+        L->capacity[l] = cap;
+        L->keys[l] = take((size_t)cap * 8);
+        L->vals[l] = take((size_t)cap * 4);
+        L->coords[l] = take(N * 16);
+        L->k3[l] = take(N * 27 * 4);
+    }
+    for (int l = 0; l < 4; ++l) {
+        L->parent_row[l] = take(N * 4);
+        L->child_k[l] = take(N * 4);
+        L->nbr_down[l] = take(N * 8 * 4);
+        L->up[l] = take(N * 8 * 4);
+    }
+    L->k5 = want_k5 ? take(N * 125 * 4) : -1;
+    L->workspace = take(pbn_coords_workspace_bytes(n));
+    L->workspace_bytes = (int64_t)pbn_coords_workspace_bytes(n);
+    return off;
+}
+
+extern "C" int pbn_coords_build(const int32_t* coords, int n, int want_k5, int x_fastest, void* arena, size_t arena_bytes,
+                                const pbn_coords_layout* L, pbn_stream_t stream) {
+    if (n < 0 || !arena || !L) return PBN_ERR_ARG;
+    pbn_coords_layout chk;
+    if (pbn_coords_arena_bytes(n, want_k5, &chk) > arena_bytes) return PBN_ERR_WORKSPACE;
+    char* A = (char*)arena;
+    auto I = [&](int64_t o) { return (int32_t*)(A + o); };
+    int32_t* counts = I(L->counts);
+    void* ws = A + L->workspace;
+    const size_t wsb = (size_t)L->workspace_bytes;
+    int rc = pbn_coords_unique(coords, nullptr, n, (uint64_t*)(A + L->keys[0]), I(L->vals[0]), L->capacity[0],
+                               I(L->unique_index), I(L->inverse), I(L->coords[0]), counts + 0, ws, wsb, stream);
+    if (rc != PBN_OK) return rc;
+    for (int l = 0; l < 4; ++l) {
+        rc = pbn_coords_stride(I(L->coords[l]), counts + l, n, 2 << l, (uint64_t*)(A + L->keys[l + 1]), I(L->vals[l + 1]),
+                               L->capacity[l + 1], I(L->coords[l + 1]), I(L->parent_row[l]), I(L->child_k[l]),
+                               I(L->nbr_down[l]), counts + l + 1, ws, wsb, stream);
+        if (rc != PBN_OK) return rc;
+    }
+    for (int l = 0; l < 5; ++l) {
+        rc = pbn_kernel_map_cube(I(L->coords[l]), counts + l, n, 3, 1 << l, x_fastest, (const uint64_t*)(A + L->keys[l]),
+                                 I(L->vals[l]), L->capacity[l], I(L->k3[l]), stream);
+        if (rc != PBN_OK) return rc;
+    }
+    if (want_k5) {
+        rc = pbn_kernel_map_cube(I(L->coords[0]), counts + 0, n, 5, 1, x_fastest, (const uint64_t*)(A + L->keys[0]),
+                                 I(L->vals[0]), L->capacity[0], I(L->k5), stream);
+        if (rc != PBN_OK) return rc;
+    }
+    for (int l = 0; l < 4; ++l) {
+        rc = pbn_up_table(I(L->parent_row[l]), I(L->child_k[l]), counts + l, n, I(L->up[l]), stream);
+        if (rc != PBN_OK) return rc;
+    }
+    return PBN_OK;
+}
+
+static inline int esize(int dtype) { return dtype == PBN_F32 ? 4 : 2; }
+
+extern "C" size_t pbn_unet_arena_bytes(const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows, int dtype,
+                                       int64_t* buf_offsets) {
+    if (!bufs || !n_rows || n_bufs < 1) return 0;
+    size_t off = 0;
+    for (int b = 0; b < n_bufs; ++b) {
+        if (b == 0) { if (buf_offsets) buf_offsets[0] = -1; continue; }  // buffer 0 is the caller's input slab
+        const size_t bytes = (size_t)n_rows[bufs[b].level] * bufs[b].width * esize(dtype);
+        if (buf_offsets) buf_offsets[b] = (int64_t)off;
+        off = a256(off + (bytes ? bytes : 16));
+    }
+    return off;
+}
+
+extern "C" int pbn_unet_forward(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs,
+                                const int32_t* n_rows, const void* input, int ld_input, const int32_t* const* k3,
+                                const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
+                                size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream) {
+    if (!ops || !bufs || !n_rows || !input || !arena || n_ops < 1 || n_bufs < 2 || n_bufs > 512) return PBN_ERR_ARG;
+    int64_t offs[512];
+    if (pbn_unet_arena_bytes(bufs, n_bufs, n_rows, dtype, offs) > arena_bytes) return PBN_ERR_WORKSPACE;
+    const int es = esize(dtype);
+    char* A = (char*)arena;
+    auto base = [&](int b) -> char* { return b == 0 ? (char*)input : A + offs[b]; };
+    auto ld = [&](int b) -> int { return b == 0 ? ld_input : bufs[b].width; };
+    for (int i = 0; i < n_ops; ++i) {
+        const pbn_unet_op& o = ops[i];
+        if (o.in_buf < 0 || o.in_buf >= n_bufs || o.out_buf < 1 || o.out_buf >= n_bufs || o.res_buf >= n_bufs ||
+            o.level_in < 0 || o.level_in > 4 || o.level_out < 0 || o.level_out > 4)
+            return PBN_ERR_ARG;
+        const int32_t* nbr = nullptr;
+        int K = 1;
+        switch (o.map_kind) {
+            case 0: break;
+            case 1: nbr = k3[o.level_out]; K = 27; break;
+            case 2: nbr = k5; K = 125; break;
+            case 3: nbr = down[o.level_in]; K = 8; break;   // level_in = fine level
+            case 4: nbr = up[o.level_out]; K = 8; break;    // level_out = fine level
+            default: return PBN_ERR_ARG;
+        }
+        if (o.map_kind != 0 && !nbr) return PBN_ERR_ARG;
+        const void* in = base(o.in_buf) + (size_t)o.in_col * es;
+        void* out = base(o.out_buf) + (size_t)o.out_col * es;
+        const void* res = o.res_buf >= 0 ? base(o.res_buf) + (size_t)o.res_col * es : nullptr;
+        const int rc = pbn_spconv_forward(in, ld(o.in_buf), nbr, K, nullptr, nullptr, n_rows[o.level_out], o.w, o.vpo,
+                                          o.n_steps, o.cout_p, o.scale, o.shift, res, o.res_buf >= 0 ? ld(o.res_buf) : 0,
+                                          o.relu, out, ld(o.out_buf), dtype, 0, splitk_ws, splitk_bytes, stream);
+        if (rc != PBN_OK) return rc;
+    }
+    return PBN_OK;
+}

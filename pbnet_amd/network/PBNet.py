@@ -94,7 +94,6 @@ class PBNet(nn.Module):
     def backbone_stage(self, feat_voxel, xyz_voxel, v2p_v1):
         with section("a3_coords"):
             inputs_v1 = ME.SparseTensor(feat_voxel, xyz_voxel)
-            inputs_v1.coordinate_manager.level(16)
         with section("a4_unet"):
             point_feat = self.MEUnet(inputs_v1)
         _sec = section("a5_heads_gather"); _sec.__enter__()
@@ -221,7 +220,6 @@ class PBNet(nn.Module):
             coords = torch.cat([row_scene.view(-1, 1).to(torch.int32),
                                 torch.floor(xyz_original[point_idx] / LOCAL_VOXEL).to(torch.int32)], 1)
             inputs_v2 = ME.SparseTensor(feat, coords)
-            inputs_v2.coordinate_manager.level(16)
         with section("a18_mask_unet"):
             mask_score = self.linear_binary(self.D_Unet(inputs_v2)).F[inputs_v2.inverse_mapping]   # [R, 1]
         if task != "test":
@@ -241,7 +239,6 @@ class PBNet(nn.Module):
             coords3 = torch.cat([proposals_idx[:, 0:1].to(torch.int32), c3], 1)
             with section("a20_score_coords"):
                 inputs_v3 = ME.SparseTensor(point_feat_p[pidx], coords3)
-                inputs_v3.coordinate_manager.level(16)
             with section("a20_score_unet"):
                 iou_feat = self.linear_IOU_feat(self.score_Unet(inputs_v3))
             with section("a20_pool_head"):

@@ -69,6 +69,7 @@ class MinkUNet(nn.Module):
         self.relu = ME.MinkowskiReLU(inplace=True)
         self.weight_initialization()
         self._fold_cache = {}
+        self._plans = {}
 
     def _make_layer(self, planes, blocks, D):
         """Mink.py:75-107 with stride 1: a 1x1 conv + BN shortcut iff the channel count changes."""
@@ -140,40 +141,138 @@ class MinkUNet(nn.Module):
             feats = self._cbr(blk.conv2, blk.norm2, h, nbr, n, relu=True, residual=res, out=out if bi == nb - 1 else None)
         return feats
 
+    # ---- native executor: the fused forward as ONE C call (csrc/executor.hip) ------------------------------------
+    def _build_plan(self, dtype):
+        """Static list of fused convolution ops over symbolic buffers: the body of Mink.py:291-354 in eval mode.
+        Buffer 0 is the input slab; levels 0..4 are tensor strides 1..16."""
+        from .. import _native as N
+        P = self.PLANES
+        keep, ops, bufs = [], [], [(0, 0)]
+        skip_c = (INIT_DIM, P[0], P[1], P[2])
+        up_c = (P[7], P[6], P[5], P[4])
+
+        def new_buf(level, width):
+            bufs.append((level, width))
+            return len(bufs) - 1
+
+        def add(conv, bn, src, map_kind, lin, lout, relu=True, res=None, out=None):
+            w, vpo, n_steps, cout_p = conv._cache.get(conv.kernel, dtype)
+            if bn is not None:
+                scale, shift = self._fold(bn, cout_p)
+            else:
+                scale = None
+                shift = _pad_vec(conv.bias.detach(), cout_p, 0.0) if conv.bias is not None else None
+            keep.extend([w, scale, shift])
+            if out is None:
+                out = (new_buf(lout, cout_p), 0)
+            op = N.UnetOp()
+            op.map_kind, op.level_in, op.level_out = map_kind, lin, lout
+            op.in_buf, op.in_col = src
+            op.res_buf, op.res_col = res if res is not None else (-1, 0)
+            op.out_buf, op.out_col = out
+            op.vpo, op.n_steps, op.cout_p, op.relu = vpo, n_steps, cout_p, int(relu)
+            op.w = w.data_ptr()
+            op.scale = scale.data_ptr() if scale is not None else None
+            op.shift = shift.data_ptr() if shift is not None else None
+            ops.append(op)
+            return out
+
+        def stage(blocks, cur, l, out=None):
+            for bi, blk in enumerate(blocks):
+                h = add(blk.conv1, blk.norm1, cur, 1, l, l)
+                res = cur
+                if blk.downsample is not None:
+                    res = add(blk.downsample[0], blk.downsample[1], cur, 0, l, l, relu=False)
+                cur = add(blk.conv2, blk.norm2, h, 1, l, l, relu=True, res=res, out=out if bi == len(blocks) - 1 else None)
+            return cur
+
+        slab = [new_buf(l, up_c[l] + skip_c[l]) for l in range(4)]
+        cur = add(self.conv0p1s1, self.bn0, (0, 0), 2, 0, 0, out=(slab[0], up_c[0]))
+        l = 0
+        for i in range(4):
+            cur = add(getattr(self, _DOWN[i]), getattr(self, _DOWN_BN[i]), cur, 3, l, l + 1)
+            l += 1
+            cur = stage(getattr(self, "block%d" % (i + 1)), cur, l, out=(slab[l], up_c[l]) if l < 4 else None)
+        for i in range(4):
+            add(getattr(self, _UP[i]), getattr(self, _UP_BN[i]), cur, 4, l, l - 1, out=(slab[l - 1], 0))
+            l -= 1
+            cur = stage(getattr(self, "block%d" % (i + 5)), (slab[l], 0), l)
+        final = add(self.final_sematic, None, cur, 0, 0, 0, relu=False)
+        cin_p = self.conv0p1s1._cache.get(self.conv0p1s1.kernel, dtype)[1] * (16 // torch.empty(0, dtype=dtype).element_size())
+        bufs[0] = (0, cin_p)
+        ops_arr = (N.UnetOp * len(ops))(*ops)
+        bufs_arr = (N.UnetBuf * len(bufs))(*[N.UnetBuf(lv, w) for lv, w in bufs])
+        return dict(ops=ops_arr, n_ops=len(ops), bufs=bufs_arr, n_bufs=len(bufs), out_buf=final[0], cin_p=cin_p,
+                    out_width=bufs[final[0]][1], keep=keep)
+
+    def _plan(self, dtype):
+        ver = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        hit = self._plans.get(dtype)
+        if hit is None or hit[0] != ver:
+            hit = (ver, self._build_plan(dtype))
+            self._plans[dtype] = hit
+        return hit[1]
+
     def _forward_fused(self, x):
+        import ctypes
+        from .. import _native as N
+        from ..MinkowskiEngine.conv import _DT, _workspace
+        cm = x.coordinate_manager
+        assert x.tensor_stride == 1
+        feats = x.F
+        dt, dev = feats.dtype, feats.device
+        plan = self._plan(dt)
+        cin_p = plan["cin_p"]
+        if feats.shape[1] < cin_p or feats.stride(1) != 1 or (feats.stride(0) * feats.element_size()) % 16 \
+                or feats.data_ptr() % 16:
+            padded = torch.zeros(feats.shape[0], cin_p, dtype=dt, device=dev)
+            padded[:, :feats.shape[1]] = feats
+            feats = padded
+        rows = cm.row_counts()
+        n_rows = (ctypes.c_int32 * 5)(*rows)
+        offs = (ctypes.c_int64 * plan["n_bufs"])()
+        lib = N.lib()
+        nbytes = lib.pbn_unet_arena_bytes(plan["bufs"], plan["n_bufs"], n_rows, _DT[dt], offs)
+        arena = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        k3, k5, down, up = cm.native_tables()
+        vp = ctypes.c_void_p
+        ws = _workspace(dev)
+        rc = lib.pbn_unet_forward(plan["ops"], plan["n_ops"], plan["bufs"], plan["n_bufs"], n_rows,
+                                  vp(feats.data_ptr()), feats.stride(0), (vp * 5)(*k3), vp(k5), (vp * 4)(*down),
+                                  (vp * 4)(*up), vp(arena.data_ptr()), nbytes, _DT[dt], vp(ws.data_ptr()), ws.numel(),
+                                  N.current_stream())
+        N.check(rc, "pbn_unet_forward")
+        o = offs[plan["out_buf"]]
+        width = plan["out_width"]
+        out = arena[o:o + rows[0] * width * feats.element_size()].view(dt).view(rows[0], width)
+        cout = self.final_sematic.kernel.shape[-1]
+        return ME.SparseTensor(out if width == cout else out[:, :cout], coordinate_manager=cm, tensor_stride=1)
+
+    def _forward_fused_py(self, x):
+        """The same fused forward issued launch by launch from Python (kept as a cross-check of the native plan)."""
         cm = x.coordinate_manager
         assert x.tensor_stride == 1
         P = self.PLANES
         dt, dev = x.F.dtype, x.F.device
-        with section("unet.maps"):
-            n = {s: cm.num_rows(s) for s in (1, 2, 4, 8, 16)}
-            k3 = {s: cm.kernel_map(s, 3) for s in (1, 2, 4, 8, 16)}
-            k5 = cm.kernel_map(1, 5)
-            ups = {s: cm.up_map(s) for s in (2, 4, 8, 16)}
-        skip_c = (INIT_DIM, P[0], P[1], P[2])                      # channels of out_p1, out_b1p2, out_b2p4, out_b3p8
-        up_c = (P[7], P[6], P[5], P[4])                            # transposed-conv channels landing at stride 1,2,4,8
+        n = {s: cm.num_rows(s) for s in (1, 2, 4, 8, 16)}
+        k3 = {s: cm.kernel_map(s, 3) for s in (1, 2, 4, 8, 16)}
+        skip_c = (INIT_DIM, P[0], P[1], P[2])
+        up_c = (P[7], P[6], P[5], P[4])
         strides = (1, 2, 4, 8)
-        # concat slabs of the decoder: [up | skip] per stride (Mink.py:323,331,339,347)
         slab = {s: torch.empty(n[s], up_c[i] + skip_c[i], dtype=dt, device=dev) for i, s in enumerate(strides)}
         skip_view = {s: slab[s][:, up_c[i]:] for i, s in enumerate(strides)}
         up_view = {s: slab[s][:, :up_c[i]] for i, s in enumerate(strides)}
-
-        with section("unet.stem"):
-            cur = self._cbr(self.conv0p1s1, self.bn0, x.F, k5, n[1], out=skip_view[1])
+        cur = self._cbr(self.conv0p1s1, self.bn0, x.F, cm.kernel_map(1, 5), n[1], out=skip_view[1])
         s = 1
-        _sec = section("unet.encoder"); _sec.__enter__()
         for i in range(4):
             cur = self._cbr(getattr(self, _DOWN[i]), getattr(self, _DOWN_BN[i]), cur, cm.down_map(s), n[2 * s])
             s *= 2
             cur = self._stage_fused(getattr(self, "block%d" % (i + 1)), cur, k3[s], n[s],
                                     out=skip_view[s] if s < 16 else None)
-        _sec.__exit__(None, None, None)
-        _sec = section("unet.decoder"); _sec.__enter__()
         for i in range(4):
-            self._cbr(getattr(self, _UP[i]), getattr(self, _UP_BN[i]), cur, ups[s], n[s // 2], out=up_view[s // 2])
+            self._cbr(getattr(self, _UP[i]), getattr(self, _UP_BN[i]), cur, cm.up_map(s), n[s // 2], out=up_view[s // 2])
             s //= 2
             cur = self._stage_fused(getattr(self, "block%d" % (i + 5)), slab[s], k3[s], n[s])
-        _sec.__exit__(None, None, None)
         fs = self.final_sematic
         packed = fs._cache.get(fs.kernel, dt)
         out = spconv_forward(cur, None, n[1], packed, shift=_pad_vec(fs.bias, packed[3], 0.0))

@@ -156,9 +156,13 @@ def test_unet_matches_golden_and_oracle(arch, golden_dir):
     m.eval()
     with torch.no_grad():
         fused = m(x).F.cpu()
+        fused_py = m._forward_fused_py(x).F.cpu()  # same plan issued launch by launch from Python
         m.FUSE_EVAL = False
         unfused = m(x).F.cpu()
         m.FUSE_EVAL = True
+    assert torch.equal(fused, fused_py), "native executor and Python-issued fused path must be bit-identical"
+    with torch.no_grad():
+        pass
     scale = max(1.0, want_eval.abs().max().item())
     assert (fused - want_eval).abs().max().item() <= TOL * scale, "fused eval path"
     assert (unfused - want_eval).abs().max().item() <= TOL * scale, "module eval path"
