@@ -55,12 +55,47 @@ def one_step(model, b, t):
 
 
 class ConvProbe(object):
-    """Instrumented pass: HIP events (torch.cuda.Event on the launching stream) around every k_spconv launch plus the
-    launch's algorithmic bytes / flops."""
+    """Instrumented pass over the same steps: HIP events on the launching stream around every k_spconv launch
+    (per-op events inside the native U-Net executor, pbn_unet_forward_timed; torch.cuda.Event around the few launches
+    issued from Python) plus each launch's algorithmic bytes / flops."""
+
+    K_OF_KIND = {0: 1, 1: 27, 2: 125, 3: 8, 4: 8}
 
     def __init__(self):
-        self.records = []
-        self.pair_cache = {}
+        self.ms = 0.0
+        self.nbytes = 0
+        self.flops = 0
+        self.launches = 0
+        self.py_records = []
+
+    def _pairs(self, cm, kind, lin, lout, rows):
+        if kind == 0:
+            return rows[lout]
+        if kind in (3, 4):
+            return rows[min(lin, lout)]           # every fine voxel has exactly one parent
+        nbr = cm.kernel_map(1 << lout, 3 if kind == 1 else 5)
+        return int((nbr >= 0).sum().item())
+
+    def unet_sink(self, model, plan, rows, cm, esz, op_ms):
+        pair_cache = {}
+        widths = [plan["bufs"][i].width for i in range(plan["n_bufs"])]
+        for i in range(plan["n_ops"]):
+            op = plan["ops"][i]
+            key = (op.map_kind, op.level_in, op.level_out)
+            if key not in pair_cache:
+                pair_cache[key] = self._pairs(cm, op.map_kind, op.level_in, op.level_out, rows)
+            pairs = pair_cache[key]
+            k = self.K_OF_KIND[op.map_kind]
+            cin = op.vpo * (16 // esz)
+            cout = op.cout_p
+            v_in, v_out = rows[op.level_in], rows[op.level_out]
+            nbytes = (v_in * cin + v_out * cout) * esz + k * cin * cout * esz + (8 * pairs if op.map_kind else 0)
+            if op.res_buf >= 0:
+                nbytes += v_out * cout * esz
+            self.nbytes += nbytes
+            self.flops += 2 * pairs * cin * cout
+            self.ms += op_ms[i]
+            self.launches += 1
 
     def install(self):
         from pbnet_amd.MinkowskiEngine import conv as C
@@ -73,42 +108,34 @@ class ConvProbe(object):
             esz = feats.element_size()
             k = 1 if nbr is None else int(nbr.shape[1])
             cin = int(feats.shape[1])
-            if nbr is None:
-                pairs, rule_bytes = int(n_out), 0
-            else:
-                key = nbr.data_ptr()
-                if key not in probe.pair_cache:
-                    probe.pair_cache[key] = int((nbr >= 0).sum().item())
-                pairs = probe.pair_cache[key]
-                rule_bytes = 8 * pairs
-            cout = cout_p
-            n_in = int(feats.shape[0])
-            nbytes = (n_in * cin + int(n_out) * cout) * esz + k * cin * cout * esz + rule_bytes
-            if kw.get("residual") is not None:
-                nbytes += int(n_out) * cout * esz
-            flops = 2 * pairs * cin * cout
+            pairs = int(n_out) if nbr is None else int((nbr >= 0).sum().item())
+            nbytes = (int(feats.shape[0]) * cin + int(n_out) * cout_p) * esz + k * cin * cout_p * esz
+            nbytes += 0 if nbr is None else 8 * pairs
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = probe._orig(feats, nbr, n_out, packed, **kw)
             e1.record()
-            probe.records.append((e0, e1, nbytes, flops))
+            probe.py_records.append((e0, e1, nbytes, 2 * pairs * cin * cout_p))
             return out
 
         C.spconv_forward = wrapped
         U.spconv_forward = wrapped
+        U.MinkUNet.OP_TIMING_SINK = self.unet_sink
         self._mods = (C, U)
 
     def remove(self):
         for m in self._mods:
             m.spconv_forward = self._orig
+        self._mods[1].MinkUNet.OP_TIMING_SINK = None
 
     def summary(self):
         torch.cuda.synchronize()
-        t_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
-        nbytes = sum(r[2] for r in self.records)
-        flops = sum(r[3] for r in self.records)
-        n = len(self.records)
-        return n, t_ms, nbytes, flops
+        for e0, e1, nbytes, flops in self.py_records:
+            self.ms += e0.elapsed_time(e1)
+            self.nbytes += nbytes
+            self.flops += flops
+            self.launches += 1
+        return self.launches, self.ms, self.nbytes, self.flops
 
 
 def cpu_baseline(cfg, model, raw):

@@ -216,6 +216,13 @@ int pbn_unet_forward(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs
                      const int32_t* const* down, const int32_t* const* up, void* arena, size_t arena_bytes, int dtype,
                      void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream);
 
+/* Measurement variant of pbn_unet_forward: brackets every op with HIP events on the launching stream, synchronises the
+ * stream before returning and fills op_ms[n_ops] (host) with the per-op durations in milliseconds. */
+int pbn_unet_forward_timed(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows,
+                           const void* input, int ld_input, const int32_t* const* k3, const int32_t* k5,
+                           const int32_t* const* down, const int32_t* const* up, void* arena, size_t arena_bytes,
+                           int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream, float* op_ms);
+
 #ifdef __cplusplus
 }
 #endif

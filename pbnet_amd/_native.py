@@ -74,6 +74,10 @@ SIGNATURES = {
     "pbn_unet_forward": (c_int, [ctypes.POINTER(UnetOp), c_int, ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32),
                                  c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp, ctypes.POINTER(ctypes.c_void_p),
                                  ctypes.POINTER(ctypes.c_void_p), c_vp, c_size, c_int, c_vp, c_size, c_vp]),
+    "pbn_unet_forward_timed": (c_int, [ctypes.POINTER(UnetOp), c_int, ctypes.POINTER(UnetBuf), c_int,
+                                       ctypes.POINTER(c_i32), c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp,
+                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_vp, c_size,
+                                       c_int, c_vp, c_size, c_vp, ctypes.POINTER(ctypes.c_float)]),
 }
 
 ERRORS = {-1: "PBN_ERR_ARG", -2: "PBN_ERR_WORKSPACE", -3: "PBN_ERR_HIP", -4: "PBN_ERR_RANGE", -5: "PBN_ERR_UNSUPPORTED"}

@@ -91,10 +91,11 @@ extern "C" size_t pbn_unet_arena_bytes(const pbn_unet_buf* bufs, int n_bufs, con
     return off;
 }
 
-extern "C" int pbn_unet_forward(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs,
-                                const int32_t* n_rows, const void* input, int ld_input, const int32_t* const* k3,
-                                const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
-                                size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream) {
+static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs,
+                             const int32_t* n_rows, const void* input, int ld_input, const int32_t* const* k3,
+                             const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
+                             size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream,
+                             hipEvent_t* events) {
     if (!ops || !bufs || !n_rows || !input || !arena || n_ops < 1 || n_bufs < 2 || n_bufs > 512) return PBN_ERR_ARG;
     int64_t offs[512];
     if (pbn_unet_arena_bytes(bufs, n_bufs, n_rows, dtype, offs) > arena_bytes) return PBN_ERR_WORKSPACE;
@@ -121,10 +122,44 @@ extern "C" int pbn_unet_forward(const pbn_unet_op* ops, int n_ops, const pbn_une
         const void* in = base(o.in_buf) + (size_t)o.in_col * es;
         void* out = base(o.out_buf) + (size_t)o.out_col * es;
         const void* res = o.res_buf >= 0 ? base(o.res_buf) + (size_t)o.res_col * es : nullptr;
+        if (events) PBN_HIP_CHECK(hipEventRecord(events[2 * i], (hipStream_t)stream));
         const int rc = pbn_spconv_forward(in, ld(o.in_buf), nbr, K, nullptr, nullptr, n_rows[o.level_out], o.w, o.vpo,
                                           o.n_steps, o.cout_p, o.scale, o.shift, res, o.res_buf >= 0 ? ld(o.res_buf) : 0,
                                           o.relu, out, ld(o.out_buf), dtype, 0, splitk_ws, splitk_bytes, stream);
         if (rc != PBN_OK) return rc;
+        if (events) PBN_HIP_CHECK(hipEventRecord(events[2 * i + 1], (hipStream_t)stream));
     }
     return PBN_OK;
+}
+
+extern "C" int pbn_unet_forward(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs,
+                                const int32_t* n_rows, const void* input, int ld_input, const int32_t* const* k3,
+                                const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
+                                size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream) {
+    return unet_forward_impl(ops, n_ops, bufs, n_bufs, n_rows, input, ld_input, k3, k5, down, up, arena, arena_bytes, dtype,
+                             splitk_ws, splitk_bytes, stream, nullptr);
+}
+
+// Measurement variant: brackets every op with HIP events on the launching stream, SYNCHRONISES the stream at the end and
+// returns the per-op durations in milliseconds (host array op_ms[n_ops]).  Used by bench.py's roofline probe only.
+extern "C" int pbn_unet_forward_timed(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs,
+                                      const int32_t* n_rows, const void* input, int ld_input, const int32_t* const* k3,
+                                      const int32_t* k5, const int32_t* const* down, const int32_t* const* up,
+                                      void* arena, size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes,
+                                      pbn_stream_t stream, float* op_ms) {
+    if (!op_ms || n_ops < 1 || n_ops > 4096) return PBN_ERR_ARG;
+    hipEvent_t* ev = new hipEvent_t[2 * (size_t)n_ops];
+    int made = 0, rc = PBN_OK;
+    for (; made < 2 * n_ops; ++made)
+        if (hipEventCreate(&ev[made]) != hipSuccess) { rc = PBN_ERR_HIP; break; }
+    if (rc == PBN_OK)
+        rc = unet_forward_impl(ops, n_ops, bufs, n_bufs, n_rows, input, ld_input, k3, k5, down, up, arena, arena_bytes,
+                               dtype, splitk_ws, splitk_bytes, stream, ev);
+    if (rc == PBN_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = PBN_ERR_HIP;
+    if (rc == PBN_OK)
+        for (int i = 0; i < n_ops; ++i)
+            if (hipEventElapsedTime(&op_ms[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) { rc = PBN_ERR_HIP; break; }
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+    delete[] ev;
+    return rc;
 }

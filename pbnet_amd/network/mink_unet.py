@@ -41,6 +41,7 @@ _UP_BN = ("bntr4", "bntr5", "bntr6", "bntr7")
 
 class MinkUNet(nn.Module):
     FUSE_EVAL = True
+    OP_TIMING_SINK = None   # callable(model, plan, rows, cm, esz, op_ms) installed by bench.py's roofline probe
 
     def __init__(self, in_channels, out_channels, D=3, arch="MinkUNet34C"):
         super().__init__()
@@ -237,10 +238,15 @@ class MinkUNet(nn.Module):
         k3, k5, down, up = cm.native_tables()
         vp = ctypes.c_void_p
         ws = _workspace(dev)
-        rc = lib.pbn_unet_forward(plan["ops"], plan["n_ops"], plan["bufs"], plan["n_bufs"], n_rows,
-                                  vp(feats.data_ptr()), feats.stride(0), (vp * 5)(*k3), vp(k5), (vp * 4)(*down),
-                                  (vp * 4)(*up), vp(arena.data_ptr()), nbytes, _DT[dt], vp(ws.data_ptr()), ws.numel(),
-                                  N.current_stream())
+        args = (plan["ops"], plan["n_ops"], plan["bufs"], plan["n_bufs"], n_rows, vp(feats.data_ptr()), feats.stride(0),
+                (vp * 5)(*k3), vp(k5), (vp * 4)(*down), (vp * 4)(*up), vp(arena.data_ptr()), nbytes, _DT[dt],
+                vp(ws.data_ptr()), ws.numel(), N.current_stream())
+        if MinkUNet.OP_TIMING_SINK is None:
+            rc = lib.pbn_unet_forward(*args)
+        else:  # bench.py's roofline probe: per-op HIP-event durations (synchronises)
+            op_ms = (ctypes.c_float * plan["n_ops"])()
+            rc = lib.pbn_unet_forward_timed(*(args + (op_ms,)))
+            MinkUNet.OP_TIMING_SINK(self, plan, rows, cm, feats.element_size(), list(op_ms))
         N.check(rc, "pbn_unet_forward")
         o = offs[plan["out_buf"]]
         width = plan["out_width"]
