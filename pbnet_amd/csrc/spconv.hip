@@ -24,6 +24,7 @@
 // parity configuration (1e-4 vs the oracle); bf16/f16 slabs use v_mfma_f32_16x16x32_{bf16,f16}.
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
+#include <cstdlib>
 #include "pbn_common.h"
 
 namespace pbn {
@@ -49,6 +50,8 @@ struct ConvArgs {
     int ksplit;          // >1: this launch writes fp32 partial sums, k_spconv_reduce applies the epilogue
     float* partial;      // [ksplit][n_out_pad][ntiles_total*16]
     int n_out_pad;
+    int cg;              // steps per barrier group (1..4)
+    int dbg;             // ablation switches for scripts/probe_conv_ablate.py (PBN_CONV_DBG); 0 in production
 };
 
 template <typename T> struct Tr;
@@ -122,41 +125,61 @@ __device__ __forceinline__ int xcd_tile(int b, int nt) {  // contiguous tile ran
 
 constexpr int CONV_TPB = 256;
 
+constexpr int CGMAX = 4;  // channel chunks (steps) per barrier group
+
+// Reduction axis: STEP s = 4 x 16-byte vectors of the flattened (offset, channel) axis; GROUP = cg consecutive steps
+// of ONE kernel offset (cg = largest divisor <= 4 of the steps per offset; 1 when an offset is narrower than a step).
+// Per group: one barrier pair to swap the weight tile in LDS; inside a group the waves run free, each prefetching
+// its next gather while the matrix cores work on the current one.
 template <typename T, int RW, int NT>
 __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
-    constexpr int ELEMS = Tr<T>::ELEMS;
+    static_assert(Tr<T>::ELEMS * sizeof(T) == 16, "one gather vector is 16 bytes");
     constexpr int TM = 4 * RW;
     constexpr int NF = RW / 16;
+    constexpr int NFRAG = TM / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = a.K;
     const int KS = K | 1;  // odd row pitch: conflict-free column reads of the rulebook tile
-    uint4* s_w = reinterpret_cast<uint4*>(smem);                                   // 2 * NT * 64 uint4
-    int* s_nbr = reinterpret_cast<int*>(smem + 2 * NT * 1024);                      // TM * KS
+    const int cg = a.cg;
+    const int n_groups = a.n_steps / cg;
+    uint4* s_w = reinterpret_cast<uint4*>(smem);                                   // cg * NT * 64 uint4
+    int* s_nbr = reinterpret_cast<int*>(smem + (size_t)cg * NT * 1024);             // TM * KS
     int* s_valid = s_nbr + TM * KS;                                                 // K fragment masks
-    int* s_steps = s_valid + ((K + 3) & ~3);                                        // n_steps + 1 (last = count)
-    int* s_masks = s_steps + a.n_steps + 1;                                         // n_steps fragment masks
+    int* s_grp = s_valid + ((K + 3) & ~3);                                          // n_groups + 1 (last = count)
+    int* s_masks = s_grp + n_groups + 1;                                            // n_groups fragment masks
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform for the compiler
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
     const int row0 = xcd_tile(blockIdx.x, gridDim.x) * TM;
     if (row0 >= n) return;
     const int tile0 = blockIdx.y * NT;
 
     for (int k = tid; k < K; k += CONV_TPB) s_valid[k] = 0;
-    __syncthreads();
-    for (int e = tid; e < TM * K; e += CONV_TPB) {
-        const int r = e / K, k = e - r * K;
-        const int p = row0 + r;
-        int v = -1;
-        if (p < n) {
-            const int row = a.row_perm ? a.row_perm[p] : p;
-            v = a.nbr ? a.nbr[(size_t)row * K + k] : row;
+    // rulebook tile -> LDS.  Full tiles of an un-permuted launch are one contiguous, 16-byte aligned block of TM*K
+    // ints: copied with independent 16-byte loads; otherwise element-wise (float-reciprocal division, exact here).
+    if (a.nbr && !a.row_perm && row0 + TM <= n && KS == K && ((TM * K) & 3) == 0) {
+        const int4* src = reinterpret_cast<const int4*>(a.nbr + (size_t)row0 * K);
+        int4* dst = reinterpret_cast<int4*>(s_nbr);
+        const int nv = (TM * K) >> 2;
+#pragma unroll 4
+        for (int e = tid; e < nv; e += CONV_TPB) dst[e] = src[e];
+    } else {
+        const float inv_k = 1.0f / (float)K;
+#pragma unroll 2
+        for (int e = tid; e < TM * K; e += CONV_TPB) {
+            const int r = (int)(((float)e + 0.5f) * inv_k), k = e - r * K;
+            const int p = row0 + r;
+            int v = -1;
+            if (p < n) {
+                const int row = a.row_perm ? a.row_perm[p] : p;
+                v = a.nbr ? a.nbr[(size_t)row * K + k] : row;
+            }
+            s_nbr[r * KS + k] = v;
         }
-        s_nbr[r * KS + k] = v;
     }
     __syncthreads();
     // per offset: bitmask of the 16-row fragments that have at least one neighbour there
-    constexpr int NFRAG = TM / 16;
     for (int e = tid; e < K * NFRAG; e += CONV_TPB) {
         const int k = e / NFRAG, fr = e - k * NFRAG;
         int any = 0;
@@ -165,19 +188,19 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
         if (any) atomicOr(&s_valid[k], 1 << fr);
     }
     __syncthreads();
-    // ordered list of the steps that touch at least one populated offset, with their fragment masks (wave 0)
+    // ordered list of the groups that touch at least one populated offset, with their fragment masks (wave 0)
     const int vpo = a.vpo;
     if (wave == 0) {
         int base = 0;
-        for (int s0 = 0; s0 < a.n_steps; s0 += 64) {
-            const int s = s0 + lane;
+        for (int g0 = 0; g0 < n_groups; g0 += 64) {
+            const int gi = g0 + lane;
             int fm = 0;
-            if (s < a.n_steps) {
+            if (gi < n_groups) {
                 if ((vpo & 3) == 0) {
-                    fm = s_valid[s / (vpo >> 2)];
+                    fm = s_valid[gi / ((vpo >> 2) / cg)];
                 } else {
-                    for (int g = 0; g < 4; ++g) {
-                        const int ko = (s * 4 + g) / vpo;
+                    for (int q = 0; q < 4; ++q) {
+                        const int ko = (gi * 4 + q) / vpo;
                         if (ko < K) fm |= s_valid[ko];
                     }
                 }
@@ -186,19 +209,19 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
             const unsigned long long m = __ballot(ok);
             if (ok) {
                 const int pos = base + __popcll(m & ((1ULL << lane) - 1ULL));
-                s_steps[pos] = s;
-                s_masks[pos] = fm;
+                s_grp[pos] = gi;
+                s_masks[pos] = fm | ((a.dbg & 1) ? 0xffff : 0);
             }
             base += __popcll(m);
         }
-        if (lane == 0) s_steps[a.n_steps] = base;
+        if (lane == 0) s_grp[n_groups] = base;
     }
     __syncthreads();
-    int ns = s_steps[a.n_steps];
-    int s_lo = 0;
-    if (a.ksplit > 1) {  // this workgroup reduces only its slice of the step list
-        s_lo = (int)((long long)ns * blockIdx.z / a.ksplit);
-        ns = (int)((long long)ns * (blockIdx.z + 1) / a.ksplit);
+    int ng = __builtin_amdgcn_readfirstlane(s_grp[n_groups]);
+    int g_lo = 0;
+    if (a.ksplit > 1) {  // this workgroup reduces only its slice of the group list
+        g_lo = (int)((long long)ng * blockIdx.z / a.ksplit);
+        ng = (int)((long long)ng * (blockIdx.z + 1) / a.ksplit);
     }
     const unsigned my_bits = ((1u << NF) - 1u) << (wave * NF);
 
@@ -208,73 +231,118 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const T* in = reinterpret_cast<const T*>(a.in);
-    const uint4* wp = reinterpret_cast<const uint4*>(a.w);
     const int g = lane >> 4, rl = lane & 15;
-    constexpr int WREGS = (NT * 64 + CONV_TPB - 1) / CONV_TPB;
+    constexpr int WPIECES = NT * 128;                                   // 8-byte pieces of one step's weight tile
+    constexpr int WREGS = (WPIECES + CONV_TPB - 1) / CONV_TPB;          // = NT/2 for even NT (no predication)
+    uint2* s_w2 = reinterpret_cast<uint2*>(s_w);
 
-    auto load_x = [&](int s, unsigned fm, uint4 (&x)[NF]) {
-        const int v = s * 4 + g;
-        int ko, cv;
-        if ((vpo & 3) == 0) { const int q = vpo >> 2; ko = s / q; cv = (s - ko * q) * 4 + g; }
-        else { ko = v / vpo; cv = v - ko * vpo; }
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            x[f] = make_uint4(0u, 0u, 0u, 0u);
-            if ((fm >> (wave * NF + f)) & 1u) {
-                const int r = wave * RW + f * 16 + rl;
-                const int src = (ko < K) ? s_nbr[r * KS + ko] : -1;
-                if (src >= 0) x[f] = *reinterpret_cast<const uint4*>(in + (size_t)src * a.ld_in + cv * ELEMS);
-            }
-        }
-    };
-    auto load_w = [&](int s, uint4 (&wr)[WREGS]) {
-#pragma unroll
-        for (int i = 0; i < WREGS; ++i) {
-            const int q = tid + i * CONV_TPB;
-            if (q < NT * 64) wr[i] = wp[((size_t)s * a.ntiles_total + tile0) * 64 + q];
-        }
-    };
-    auto store_w = [&](int buf, const uint4 (&wr)[WREGS]) {
-#pragma unroll
-        for (int i = 0; i < WREGS; ++i) {
-            const int q = tid + i * CONV_TPB;
-            if (q < NT * 64) s_w[buf * NT * 64 + q] = wr[i];
-        }
-    };
+    // Both operands come in through buffer resources: a gather is ONE instruction with a 32-bit per-lane byte offset,
+    // and a fragment without a neighbour simply uses an out-of-range offset -- the hardware bounds check returns
+    // zeros, so the inner loop has no exec-mask branches and no 64-bit address arithmetic.  (Slabs must stay < 2 GiB.)
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, 0x80000000u, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;  // >= num_records: the bounds check turns the load into zeros
+    const unsigned ld_bytes = (unsigned)a.ld_in * (unsigned)sizeof(T);
+    const int vshift = (vpo == 2) ? 1 : 0;
+    const int spo = (vpo & 3) == 0 ? (vpo >> 2) : 1;   // steps per offset (wide layers)
+    const int gpo = spo / cg;                            // groups per offset (wide layers)
+    const unsigned w_tile_bytes = (unsigned)a.ntiles_total * 1024u;   // one step, all channel tiles
+    const unsigned w_voff = (unsigned)tid * 8u;
 
-    if (ns > s_lo) {
-        uint4 xcur[NF], xnext[NF], wr[WREGS];
-        unsigned fcur = (unsigned)s_masks[s_lo], fnext = 0;
-        load_w(s_steps[s_lo], wr);
-        load_x(s_steps[s_lo], fcur, xcur);
-        store_w(0, wr);
-        __syncthreads();
-        for (int si = s_lo; si < ns; ++si) {
-            const int cur = (si - s_lo) & 1;
-            const bool more = si + 1 < ns;
-            if (more) {
-                const int sn = s_steps[si + 1];
-                fnext = (unsigned)s_masks[si + 1];
-                load_w(sn, wr);
-                load_x(sn, fnext, xnext);
+    // per-group gather offsets: every chunk of a group reads the same neighbour row at +64 B per chunk
+#define PBN_GROUP_ROWS(GI, VOFF)                                                                                      \
+    {                                                                                                                 \
+        int ko_, cv_;                                                                                                 \
+        if ((vpo & 3) == 0) { ko_ = (GI) / gpo; cv_ = ((GI) - ko_ * gpo) * cg * 4 + g; }                              \
+        else { const int v_ = (GI) * 4 + g; ko_ = v_ >> vshift; cv_ = v_ & (vpo - 1); }                               \
+        _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                              \
+            const int r_ = wave * RW + f * 16 + rl;                                                                   \
+            const int src_ = (ko_ < K) ? s_nbr[r_ * KS + ko_] : -1;                                                   \
+            VOFF[f] = (src_ >= 0 && !(a.dbg & 4)) ? (unsigned)src_ * ld_bytes + (unsigned)cv_ * 16u : OOB;            \
+        }                                                                                                             \
+    }
+#define PBN_LOAD_X(VOFF, C, X)                                                                                        \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int f = 0; f < NF; ++f)                                                                \
+            X[f] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, VOFF[f], (C) * 64, 0));     \
+    }
+#define PBN_LOAD_WGROUP(GI)                                                                                           \
+    {                                                                                                                 \
+        const unsigned gbase_ = ((unsigned)(GI) * cg * a.ntiles_total + tile0) * 1024u;                               \
+        _Pragma("unroll") for (int c = 0; c < CGMAX; ++c) {                                                           \
+            if (c < cg) {                                                                                             \
+                _Pragma("unroll") for (int i = 0; i < WREGS; ++i) {                                                   \
+                    const unsigned vo_ = (WPIECES % CONV_TPB == 0 || tid + i * CONV_TPB < WPIECES)                    \
+                                             ? w_voff + i * (CONV_TPB * 8u) : OOB;                                    \
+                    wr[c][i] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(                        \
+                                                           rs_w, (a.dbg & 8) ? OOB : vo_, gbase_ + c * w_tile_bytes, 0)); \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
+#define PBN_STORE_WGROUP()                                                                                            \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int c = 0; c < CGMAX; ++c) {                                                           \
+            if (c < cg) {                                                                                             \
+                _Pragma("unroll") for (int i = 0; i < WREGS; ++i) {                                                   \
+                    const int q_ = tid + i * CONV_TPB;                                                                \
+                    if (WPIECES % CONV_TPB == 0 || q_ < WPIECES) s_w2[c * WPIECES + q_] = wr[c][i];                   \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
+
+    if (ng > g_lo && !(a.dbg & 16)) {
+        // Software pipeline at GROUP granularity: while the matrix cores work through group i (cg chunks x NT x NF MFMAs),
+        // the weight tile AND every gather of group i+1 are already in flight; they are consumed after the next barrier.
+        uint4 xc[CGMAX][NF], xn[CGMAX][NF];
+        unsigned vnext[NF];
+        uint2 wr[CGMAX][WREGS];
+        int gcur = __builtin_amdgcn_readfirstlane(s_grp[g_lo]);
+        unsigned fcur = (unsigned)__builtin_amdgcn_readfirstlane(s_masks[g_lo]);
+        PBN_LOAD_WGROUP(gcur);
+        PBN_GROUP_ROWS(gcur, vnext);
+#pragma unroll
+        for (int c = 0; c < CGMAX; ++c)
+            if (c < cg) { PBN_LOAD_X(vnext, c, xn[c]); }
+        for (int gi = g_lo; gi < ng; ++gi) {
+            // swap the weight tile: everybody is done with the previous group's tile, then publish this group's
+            __syncthreads();
+            PBN_STORE_WGROUP();
+#pragma unroll
+            for (int c = 0; c < CGMAX; ++c)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) xc[c][f] = xn[c][f];
+            __syncthreads();
+            const bool active = (fcur & my_bits) && !(a.dbg & 2);  // wave-uniform: any of this wave's fragments populated
+            if (gi + 1 < ng) {
+                const int gnext = __builtin_amdgcn_readfirstlane(s_grp[gi + 1]);
+                fcur = (unsigned)__builtin_amdgcn_readfirstlane(s_masks[gi + 1]);
+                PBN_LOAD_WGROUP(gnext);
+                PBN_GROUP_ROWS(gnext, vnext);
+#pragma unroll
+                for (int c = 0; c < CGMAX; ++c)
+                    if (c < cg) { PBN_LOAD_X(vnext, c, xn[c]); }
             }
-            if (fcur & my_bits) {
+            if (active) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const uint4 wf = s_w[cur * NT * 64 + t * 64 + lane];
+                for (int c = 0; c < CGMAX; ++c) {
+                    if (c < cg) {
 #pragma unroll
-                    for (int f = 0; f < NF; ++f)
-                        if ((fcur >> (wave * NF + f)) & 1u) mfma_step<T>(wf, xcur[f], acc[f][t]);
+                        for (int t = 0; t < NT; ++t) {
+                            const uint4 wf = s_w[(c * NT + t) * 64 + lane];
+#pragma unroll
+                            for (int f = 0; f < NF; ++f) mfma_step<T>(wf, xc[c][f], acc[f][t]);
+                        }
+                    }
                 }
             }
-            if (more) store_w(cur ^ 1, wr);
-            __syncthreads();
-#pragma unroll
-            for (int f = 0; f < NF; ++f) xcur[f] = xnext[f];
-            fcur = fnext;
         }
     }
+#undef PBN_GROUP_ROWS
+#undef PBN_LOAD_X
+#undef PBN_LOAD_WGROUP
+#undef PBN_STORE_WGROUP
 
     if (a.ksplit > 1) {  // raw fp32 partial sums, tile-position rows; the epilogue runs in k_spconv_reduce
         const int ldp = a.ntiles_total * 16;
@@ -293,6 +361,7 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     }
 
     // epilogue: lane holds channels c0..c0+3 of output row (wave*RW + f*16 + rl)
+    if (a.dbg & 32) return;
     T* out = reinterpret_cast<T*>(a.out);
     const T* res = reinterpret_cast<const T*>(a.residual);
 #pragma unroll
@@ -358,7 +427,15 @@ template <typename T, int RW, int NT>
 int launch_one(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes, hipStream_t stream) {
     constexpr int TM = 4 * RW;
     const int KS = a.K | 1;
-    const size_t lds = 2 * NT * 1024 + sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 2 * (size_t)a.n_steps + 1);
+    // steps per barrier group: the largest divisor <= 4 of the steps per offset (1 when offsets are narrower than a step)
+    a.cg = 1;
+    if ((a.vpo & 3) == 0) {
+        const int spo = a.vpo >> 2;
+        for (int c = CGMAX; c >= 1; --c)
+            if (spo % c == 0) { a.cg = c; break; }
+    }
+    const int n_groups = a.n_steps / a.cg;
+    const size_t lds = (size_t)a.cg * NT * 1024 + sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 2 * (size_t)n_groups + 1);
     if (lds > 160 * 1024) return PBN_ERR_UNSUPPORTED;
     auto kern = k_spconv<T, RW, NT>;
     if (lds > 64 * 1024)
@@ -370,9 +447,9 @@ int launch_one(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes
     a.partial = nullptr;
     a.n_out_pad = tiles * TM;
     const long long wgs = (long long)tiles * ngroups;
-    if (workspace && wgs < 384 && a.n_steps >= 8) {
+    if (workspace && wgs < 384 && n_groups >= 8) {
         long long want = (768 + wgs - 1) / wgs;
-        const long long by_steps = a.n_steps / 4;
+        const long long by_steps = n_groups / 2;
         const long long by_ws = (long long)(workspace_bytes / ((size_t)a.n_out_pad * a.ntiles_total * 16 * sizeof(float)));
         if (want > by_steps) want = by_steps;
         if (want > by_ws) want = by_ws;
@@ -442,6 +519,8 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, const int32_t*
     a.K = n_offsets; a.vpo = vecs_per_offset; a.n_steps = n_steps; a.ntiles_total = cout_padded / 16; a.n_out = n_out;
     a.relu = relu;
     a.ksplit = 1; a.partial = nullptr; a.n_out_pad = 0;
+    static const int dbg_env = getenv("PBN_CONV_DBG") ? atoi(getenv("PBN_CONV_DBG")) : 0;
+    a.dbg = dbg_env;
     float* ws = reinterpret_cast<float*>(workspace);
     if (((uintptr_t)workspace) & 15) ws = nullptr;
     if (rows_per_wave != 16 && rows_per_wave != 32) rows_per_wave = (n_out >= 64 * 1024) ? 32 : 16;

@@ -1,0 +1,36 @@
+"""Single-layer conv timing (S150 stride-1 level, 96->96, K=27, bf16) under PBN_CONV_DBG ablations."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import pbnet_amd.MinkowskiEngine as ME
+from pbnet_amd import synth
+from pbnet_amd.MinkowskiEngine.conv import spconv_forward
+dev = "cuda:0"
+batch, _, _ = synth.make_val_batch(seed=2, copies=1)
+coords = torch.from_numpy(batch["xyz_voxel"]).to(dev)
+cm = ME.CoordinateManager(coords)
+torch.manual_seed(0)
+def run(level, cin, cout, k=3, rw=0):
+    stride = 1 << level
+    n = cm.num_rows(stride)
+    nbr = cm.kernel_map(stride, k)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=k, dimension=3).to(dev)
+    x = torch.randn(n, cin, device=dev).to(torch.bfloat16)
+    packed = conv._cache.get(conv.kernel, torch.bfloat16)
+    for _ in range(3): spconv_forward(x, nbr, n, packed, rows_per_wave=rw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): spconv_forward(x, nbr, n, packed, rows_per_wave=rw)
+    e1.record(); torch.cuda.synchronize()
+    pairs = int((nbr >= 0).sum().item())
+    # fragment-level fill: fraction of (16-row fragment, offset) pairs with at least one neighbour
+    nb16 = (nbr[: n // 16 * 16].view(-1, 16, nbr.shape[1]) >= 0).any(1).float().mean().item()
+    t = e0.elapsed_time(e1) / 10 * 1e3
+    print("dbg=%s level=%d rows=%d %d->%d K=%d rw=%d: %.1f us  (pairs/row %.2f, fragment fill %.2f, %.1f TFLOP/s real)" % (
+        os.environ.get("PBN_CONV_DBG", "0"), level, n, cin, cout, k ** 3, rw, t, pairs / n, nb16, 2 * pairs * cin * cout / t / 1e6))
+run(0, 96, 96)
+run(0, 96, 96, rw=16)
+run(1, 96, 96)
+run(2, 128, 128)
+run(3, 256, 256)
+run(4, 256, 256)
