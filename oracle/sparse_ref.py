@@ -195,13 +195,16 @@ def basic_block(x, sd, prefix, cm, stride, training):
     return torch.relu(out + res)
 
 
-def minkunet_forward(sd, arch, feats, coords, training=False, dtype=torch.float32, cm=None, taps=None):
+def minkunet_forward(sd, arch, feats, coords, training=False, dtype=torch.float32, cm=None, taps=None, detach=True):
     """MinkUNetBase.forward (Mink.py:291-354) on a state dict with the reference's parameter names.
 
     feats [V,Cin], coords int [V,4] (b,x,y,z), unique.  Returns features [V,Cout] in input row order."""
     cfg = ARCH[arch]
-    sd = {k: v.detach().to("cpu").to(dtype) if v.is_floating_point() else v.detach().cpu() for k, v in sd.items()}
-    x = feats.detach().cpu().to(dtype)
+    if detach:
+        sd = {k: v.detach().to("cpu").to(dtype) if v.is_floating_point() else v.detach().cpu() for k, v in sd.items()}
+        x = feats.detach().cpu().to(dtype)
+    else:  # keep the autograd graph: reference gradients for the training-path tests
+        x = feats
     cm = cm or CoordinateManager(np.asarray(coords))
     n = {s: cm.get_coords(s).shape[0] for s in (1, 2, 4, 8, 16)}
 

@@ -119,20 +119,59 @@ def _pad_vec(v, cout_p, fill):
     return out
 
 
+WGRAD_CHUNK_BYTES = 192 << 20
+
+
+def _wgrad(feats, grad_out, nbr, cin, cout):
+    """dW[k] = sum over rule pairs (i, o) at offset k of feats[i]^T grad_out[o]: a row gather followed by ONE plain
+    dense GEMM per offset chunk ([kc*Cin, V] x [V, Cout], rocBLAS through torch.matmul -- the contraction itself has no
+    sparse structure left once the rows are gathered).  fp32 result."""
+    if nbr is None:
+        return (feats[:, :cin].t() @ grad_out[:, :cout]).float().unsqueeze(0)
+    v, k = nbr.shape
+    dw = torch.empty(k, cin, cout, dtype=torch.float32, device=feats.device)
+    f = feats[:, :cin]
+    g = grad_out[:, :cout].contiguous()
+    kc = max(1, min(k, WGRAD_CHUNK_BYTES // max(1, v * cin * f.element_size())))
+    for k0 in range(0, k, kc):
+        idx = nbr[:, k0:k0 + kc].long()                                       # [V, kc]
+        a = f[idx.clamp(min=0)] * (idx >= 0).unsqueeze(-1).to(f.dtype)         # [V, kc, Cin], zeros where no neighbour
+        dw[k0:k0 + kc] = (a.reshape(v, -1).t() @ g).float().view(-1, cin, cout)
+    return dw
+
+
 class _ConvFn(torch.autograd.Function):
-    """Forward only for now; the backward kernels (dgrad / wgrad) are the training row of SURVEY 8f."""
+    """Sparse convolution with autograd.  forward / dgrad run on the implicit-GEMM kernel (the input gradient of an
+    output-stationary table is the same kind of table: the mirrored offset of the same map for odd kernels, the up table
+    for a k=2,s=2 convolution, the down table for its transpose); wgrad is a gather + library GEMM (see _wgrad)."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, bias, nbr, n_out, cache):
+    def forward(ctx, feats, kernel, bias, nbr, n_out, cache, dgrad_nbr, flip):
         packed = cache.get(kernel, feats.dtype)
         shift = None if bias is None else _pad_vec(bias, packed[3], 0.0)
         out = spconv_forward(feats, nbr, n_out, packed, shift=shift)
         cout = kernel.shape[-1]
+        ctx.save_for_backward(feats, kernel)
+        ctx.nbr, ctx.dgrad_nbr, ctx.flip, ctx.has_bias = nbr, dgrad_nbr, flip, bias is not None
         return out if out.shape[1] == cout else out[:, :cout]
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError("sparse convolution backward is not built yet (training row, DESIGN.md)")
+        feats, kernel = ctx.saved_tensors
+        k3 = kernel if kernel.dim() == 3 else kernel.unsqueeze(0)
+        cin, cout = k3.shape[1], k3.shape[2]
+        grad_out = grad_out.contiguous()
+        grad_feats = grad_kernel = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            wt = k3.detach().flip(0) if ctx.flip else k3.detach()
+            packed = pack_weight(wt.transpose(1, 2).contiguous(), grad_out.dtype)   # [K, Cout, Cin]
+            gi = spconv_forward(grad_out, ctx.dgrad_nbr, feats.shape[0], packed)
+            grad_feats = gi if gi.shape[1] == feats.shape[1] else gi[:, :feats.shape[1]]
+        if ctx.needs_input_grad[1]:
+            grad_kernel = _wgrad(feats, grad_out, ctx.nbr, cin, cout).to(kernel.dtype).view_as(kernel)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = grad_out.float().sum(0, keepdim=True)
+        return grad_feats, grad_kernel, grad_bias, None, None, None, None, None
 
 
 class MinkowskiConvolutionBase(nn.Module):
@@ -161,22 +200,24 @@ class MinkowskiConvolutionBase(nn.Module):
                 self.bias.uniform_(-stdv, stdv)
 
     def _map(self, x):
+        """(forward table, output stride, table of the input gradient, mirror-the-offsets flag)."""
         cm, s = x.coordinate_manager, x.tensor_stride
         if self.is_transpose:
             assert self.kernel_size == 2 and self.stride == 2, "only k=2,s=2 transposed convolutions are on the path"
-            return cm.up_map(s), s // 2
+            return cm.up_map(s), s // 2, cm.down_map(s // 2), False
         if self.kernel_size == 1 and self.stride == 1:
-            return None, s
+            return None, s, None, False
         if self.stride == 2:
             assert self.kernel_size == 2, "only k=2,s=2 strided convolutions are on the path"
-            return cm.down_map(s), s * 2
+            return cm.down_map(s), s * 2, cm.up_map(s * 2), False
         assert self.stride == 1 and self.kernel_size % 2 == 1
-        return cm.kernel_map(s, self.kernel_size), s
+        nbr = cm.kernel_map(s, self.kernel_size)
+        return nbr, s, nbr, True   # centred cube: offset K-1-k is the mirror of offset k, same table serves dgrad
 
     def forward(self, x):
-        nbr, out_stride = self._map(x)
+        nbr, out_stride, dgrad_nbr, flip = self._map(x)
         n_out = x.coordinate_manager.num_rows(out_stride)
-        feats = _ConvFn.apply(x.F, self.kernel, self.bias, nbr, n_out, self._cache)
+        feats = _ConvFn.apply(x.F, self.kernel, self.bias, nbr, n_out, self._cache, dgrad_nbr, flip)
         return SparseTensor(feats, coordinate_manager=x.coordinate_manager, tensor_stride=out_stride)
 
     def extra_repr(self):
@@ -205,11 +246,24 @@ class _LinearFn(torch.autograd.Function):
         shift = None if bias is None else _pad_vec(bias, packed[3], 0.0)
         out = spconv_forward(feats, None, feats.shape[0], packed, shift=shift)
         cout = weight.shape[0]
+        ctx.save_for_backward(feats, weight)
+        ctx.has_bias = bias is not None
         return out if out.shape[1] == cout else out[:, :cout]
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError("linear backward through the HIP path is not built yet")
+        feats, weight = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        grad_feats = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            packed = pack_weight(weight.detach().unsqueeze(0), grad_out.dtype)      # [1, out, in]: grad_x = grad_out @ W
+            gi = spconv_forward(grad_out, None, feats.shape[0], packed)
+            grad_feats = gi if gi.shape[1] == feats.shape[1] else gi[:, :feats.shape[1]]
+        if ctx.needs_input_grad[1]:
+            grad_weight = (grad_out.t() @ feats).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = grad_out.float().sum(0).to(weight.dtype)
+        return grad_feats, grad_weight, grad_bias, None
 
 
 class MinkowskiLinear(nn.Module):

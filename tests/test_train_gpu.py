@@ -1,0 +1,149 @@
+"""GPU tier, training path (BASELINE configs[2]): gradients of the sparse convolutions (dgrad on the implicit-GEMM
+kernel, wgrad as gather + GEMM) against torch autograd through the CPU oracle's gather-mm-index_add convolution."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_ref as R
+import pbnet_amd.MinkowskiEngine as ME
+from pbnet_amd import synth
+from pbnet_amd.config import get_config
+from pbnet_amd.network.Mink import Mink_unet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _coords(seed=51, batch=2):
+    sc = synth.synth_room(seed=seed, pitch=0.0225, room=(0.6, 0.5, 0.4), n_boxes=1)
+    q, _, _ = synth.voxelize_numpy(sc["xyz"], 0.02)
+    parts = [np.concatenate([np.full((len(q), 1), b, np.int32), q + np.array([7 * b, 0, 0], np.int32)], 1) for b in range(batch)]
+    return np.concatenate(parts, 0).astype(np.int32)
+
+
+def _rel(a, b):
+    return (a - b).norm().item() / max(b.norm().item(), 1e-12)
+
+
+@pytest.mark.parametrize("kind", ["k3", "k5", "down", "up", "1x1", "linear"])
+def test_convolution_gradients(kind):
+    coords = _coords()
+    cm_ref = R.CoordinateManager(coords)
+    torch.manual_seed(7)
+    cin, cout = (6, 32) if kind == "k5" else (32, 48)
+    n1, n2 = len(coords), cm_ref.get_coords(2).shape[0]
+    if kind in ("k3", "k5", "1x1"):
+        k = {"k3": 3, "k5": 5, "1x1": 1}[kind]
+        mod = ME.MinkowskiConvolution(cin, cout, kernel_size=k, bias=(kind == "1x1"), dimension=3)
+        n_in, n_out, in_stride = n1, n1, 1
+        ref = lambda x, w, b: R.conv(x, w, None if k == 1 else cm_ref.get_map(1, 1, k), n1, bias=b)
+    elif kind == "down":
+        mod = ME.MinkowskiConvolution(cin, cout, kernel_size=2, stride=2, dimension=3)
+        n_in, n_out, in_stride = n1, n2, 1
+        ref = lambda x, w, b: R.conv(x, w, cm_ref.get_map(1, 2, 2), n2)
+    elif kind == "up":
+        mod = ME.MinkowskiConvolutionTranspose(cin, cout, kernel_size=2, stride=2, dimension=3)
+        n_in, n_out, in_stride = n2, n1, 2
+        ref = lambda x, w, b: R.conv_transpose(x, w, cm_ref.get_map(1, 2, 2), n1)
+    else:
+        mod = ME.MinkowskiLinear(cin, cout, bias=True)
+        n_in, n_out, in_stride = n1, n1, 1
+        ref = None
+    x0 = torch.randn(n_in, cin)
+    gy = torch.randn(n_out, cout)
+    # reference gradients (CPU autograd)
+    xr = x0.clone().requires_grad_(True)
+    if kind == "linear":
+        wr = mod.linear.weight.detach().clone().requires_grad_(True)
+        br = mod.linear.bias.detach().clone().requires_grad_(True)
+        yr = xr @ wr.t() + br
+    else:
+        wr = mod.kernel.detach().clone().requires_grad_(True)
+        br = mod.bias.detach().clone().requires_grad_(True) if mod.bias is not None else None
+        yr = ref(xr, wr, br)
+    (yr * gy).sum().backward()
+    # device path
+    mod = mod.to(DEV)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(DEV))
+    xd = x0.to(DEV).requires_grad_(True)
+    yd = mod(ME.SparseTensor(xd, coordinate_manager=cm, tensor_stride=in_stride)).F
+    assert _rel(yd.detach().cpu(), yr.detach()) < 1e-5
+    (yd * gy.to(DEV)).sum().backward()
+    assert _rel(xd.grad.cpu(), xr.grad) < 1e-5, "input gradient"
+    w_dev = mod.linear.weight if kind == "linear" else mod.kernel
+    assert _rel(w_dev.grad.cpu(), wr.grad) < 1e-5, "weight gradient"
+    if br is not None:
+        b_dev = mod.linear.bias if kind == "linear" else mod.bias
+        assert _rel(b_dev.grad.cpu().view(-1), br.grad.view(-1)) < 1e-5, "bias gradient"
+
+
+def test_unet_training_step_gradients():
+    """MinkUNet14A in train mode: loss.backward() through every layer kind; gradients vs oracle autograd."""
+    coords = _coords(seed=52)
+    torch.manual_seed(22)
+    net = Mink_unet(6, 32, arch="MinkUNet14A")
+    feats = torch.randn(len(coords), 6)
+    target = torch.randn(len(coords), 32)
+    # oracle
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+          for k, v in net.state_dict().items()}
+    xr = feats.clone().requires_grad_(True)
+    out_r = R.minkunet_forward(sd, "MinkUNet14A", xr, coords, training=True, detach=False)
+    loss_r = ((out_r - target) ** 2).mean()
+    loss_r.backward()
+    # device
+    net = net.to(DEV).train()
+    xd = feats.to(DEV).requires_grad_(True)
+    out_d = net(ME.SparseTensor(xd, torch.from_numpy(coords).to(DEV))).F
+    loss_d = ((out_d - target.to(DEV)) ** 2).mean()
+    loss_d.backward()
+    assert abs(loss_d.item() - loss_r.item()) <= 1e-4 * max(1.0, abs(loss_r.item()))
+    assert _rel(xd.grad.cpu(), xr.grad) < 1e-3
+    named = dict(net.named_parameters())
+    checked = 0
+    for name in ("conv0p1s1.kernel", "conv1p1s2.kernel", "block1.0.conv1.kernel", "block4.0.conv2.kernel",
+                 "block5.0.downsample.0.kernel", "convtr4p16s2.kernel", "convtr7p2s2.kernel", "block8.0.conv2.kernel",
+                 "final_sematic.kernel", "final_sematic.bias", "bn0.bn.weight", "block3.0.norm1.bn.bias"):
+        g_dev, g_ref = named[name].grad, sd[name].grad
+        assert g_dev is not None and g_ref is not None, name
+        assert _rel(g_dev.cpu(), g_ref) < 2e-3, name
+        checked += 1
+    assert checked == 12
+    assert all(p.grad is not None for p in net.parameters())
+
+
+def test_pbnet_training_step_runs():
+    """model_fn (PBNet.py:349-444) with the cluster stage on: forward, losses (incl. pbnet_ops.get_iou), backward."""
+    from pbnet_amd.network.PBNet import PBNet, model_fn
+    cfg = get_config(batch_size=2, cluster_epoch=0)
+    torch.manual_seed(22)
+    model = PBNet(cfg).to(DEV).train()
+    batch_np, teacher_np, _ = synth.make_val_batch(seed=3, copies=2, room=(1.2, 1.0, 0.8), n_boxes=4, pitch=0.03,
+                                                   classes=(17, 10))
+    t = torch.from_numpy
+    batch = {k: t(v) for k, v in batch_np.items()}
+    n = batch["xyz_original"].shape[0]
+    ins = batch["ins"]
+    n_inst = int(ins.max().item()) + 1
+    sem = teacher_np["sem_score"].argmax(1)
+    info = torch.zeros(n, 9)
+    pointnum = []
+    for i in range(n_inst):
+        m = ins == i
+        pointnum.append(int(m.sum()))
+        if m.any():
+            info[m, 0:3] = batch["xyz_original"][m].mean(0)
+    batch.update(sem=t(sem).long(), inst_info=info, instance_pointnum=torch.tensor(pointnum, dtype=torch.int32))
+    # teacher-forced heads so that the grouping stage finds instances (random heads cannot): patch forward's hook
+    teacher = {k: t(v) for k, v in teacher_np.items()}
+    orig_forward = model.forward
+    model.forward = lambda *a, **kw: orig_forward(*a, teacher=teacher, **kw)
+    loss, pred, visual, meter = model_fn(batch, model, 1, cfg, "train")
+    assert torch.isfinite(loss)
+    assert "mask_loss" in visual and pred["proposals"][1].shape[0] > 1
+    loss.backward()
+    got = [n_ for n_, p in model.named_parameters() if p.grad is not None]
+    # the mask / score branches learn through their own U-Nets; the backbone through the mask features
+    for prefix in ("D_Unet.", "score_Unet.", "linear_binary.", "linear_IOU.", "MEUnet."):
+        assert any(g.startswith(prefix) for g in got), prefix
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
