@@ -243,10 +243,13 @@ class PBNet(nn.Module):
                 iou_feat = self.linear_IOU_feat(self.score_Unet(inputs_v3))
             with section("a20_pool_head"):
                 # global max + avg pooling per proposal (PBNet.py:274-276); rows are grouped by proposal id
-                from ..MinkowskiEngine.nn import segment_pool, _PooledTensor
-                n_prop = int(proposals_offset.shape[0]) - 1
-                mx, av = segment_pool(iou_feat.F, inputs_v3.C[:, 0], n_prop)
-                global_feat = _PooledTensor((mx + av).to(iou_feat.F.dtype))
+                if torch.is_grad_enabled():      # training: differentiable torch reductions
+                    global_feat = self.global_max_pool(iou_feat) + self.global_avg_pool(iou_feat)
+                else:                            # inference: one deterministic segment-pool kernel
+                    from ..MinkowskiEngine.nn import segment_pool, _PooledTensor
+                    n_prop = int(proposals_offset.shape[0]) - 1
+                    mx, av = segment_pool(iou_feat.F, inputs_v3.C[:, 0], n_prop)
+                    global_feat = _PooledTensor((mx + av).to(iou_feat.F.dtype))
                 out["clt_scores"] = self.linear_IOU(global_feat).F.view(-1)
         else:
             out["clt_scores"] = torch.zeros(0, dtype=torch.float32, device=dev)
