@@ -242,23 +242,30 @@ __global__ __launch_bounds__(TPB) void k_union(const float4* __restrict__ spt, c
                                               float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
                                               unsigned hmask, const int* __restrict__ hstart,
                                               const int* __restrict__ hcount, int* parent,
-                                              const int* __restrict__ cell_rep) {
+                                              const int* __restrict__ cell_rep, const int* __restrict__ sslot, int pass) {
+    // pass 0: every HP chains to its cell representative; only the representatives (and points of untrusted cells)
+    //         look across cells -- a few hundred threads do almost all merging without contention;
+    // (k_compress flattens the forest in between)
+    // pass 1: every HP repeats the cross-cell search, which is now a cached parent compare for all merged pairs and
+    //         only does real work for the edges a representative could not witness.
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= n) return;
     const float4 me = spt[p];
     const int wi = __float_as_int(me.w);
     if (wi >= 0) return;  // LP: never expands (binary_cuda_functions.cu:209)
     const int i = wi & 0x7fffffff;
-    int ri = i;
+    const int my_rep = cell_rep[sslot[p]];
+    const bool own_trusted = cell_trusted(cell_coord(me.x, inv_cell), cell_coord(me.y, inv_cell), cell_coord(me.z, inv_cell));
+    int ri = (pass == 0) ? i : parent[i];
+    if (pass == 0 && own_trusted) {
+        if (my_rep != i) { uf_union(parent, i, my_rep); return; }  // chained; the representative does the rest
+    }
     for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount,
                             [&](int beg, int end, int slot, bool trusted, bool same) {
         const int rep = cell_rep[slot];
         if (rep == BIG) return;  // no HP in that cell
         if (trusted) {
-            if (same) {
-                if (rep != i) ri = uf_union(parent, ri, rep);
-                return;
-            }
+            if (same) return;    // own trusted cell: chained in pass 0
             // plain (possibly stale) read: a stale parent is a former ancestor, i.e. provably the same set
             if (rep == ri || parent[rep] == ri) return;
             ri = uf_find(parent, ri);
@@ -281,6 +288,17 @@ __global__ __launch_bounds__(TPB) void k_union(const float4* __restrict__ spt, c
             }
         }
     });
+}
+
+// flatten the forest between the two union passes: afterwards parent[i] is i's root for every HP
+__global__ __launch_bounds__(TPB) void k_compress(const float4* __restrict__ spt, int n, int* parent) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= n) return;
+    const int wi = __float_as_int(spt[p].w);
+    if (wi >= 0) return;
+    const int i = wi & 0x7fffffff;
+    const int r = uf_find(parent, i);
+    if (r != i) atomicMin(&parent[i], r);
 }
 
 // HP: lab = root (general mode: also register the smallest same-class HP of the component)
@@ -364,10 +382,17 @@ __global__ __launch_bounds__(TPB) void k_copy_i32(const int* __restrict__ src, i
 
 // a14: cluster population (HPs + border LPs) per seed
 __global__ __launch_bounds__(TPB) void k_sizes(const int* __restrict__ lab, int n, int* __restrict__ size) {
+    // a wave's lanes mostly share a handful of seeds: one atomic per distinct seed per wave instead of one per point
     const int i = blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    const int s = lab[i];
-    if (s >= 0) atomicAdd(&size[s], 1);
+    int s = (i < n) ? lab[i] : -1;
+    unsigned long long todo = __ballot(s >= 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int ls = __shfl(s, leader, 64);
+        const unsigned long long same = __ballot(s == ls);
+        if (lane_id() == leader) atomicAdd(&size[ls], __popcll(same));
+        todo &= ~same;
+    }
 }
 
 // a14: keep flag per seed: dropped iff float(size) < mean_count[sem-2] * para_f (binary.cu:255-256)
@@ -488,6 +513,16 @@ __global__ __launch_bounds__(TPB) void k_noise_nn(const int* __restrict__ noise_
 // is compacted (ballot prefix) into LDS; lanes 0..2 then advance the sequential running mean M += (p - M)/N
 // (binary_cuda_functions.cu:237-239) of x, y, z -- three independent dependency chains in one instruction stream, the
 // IEEE division being the critical path that bit-exactness imposes.  The next chunk's loads are issued before the chain.
+// RN(d / n) for an integer-valued n < 2^24 - 1 given y = RN(1/n); falls back to the IEEE division outside the range
+// where the correction step is exact (tiny, huge or non-finite d).
+__device__ __forceinline__ float exact_quotient(float d, float n, float y) {
+    const float ad = fabsf(d);
+    if (!(ad >= 1e-30f && ad <= 1e30f)) return __fdiv_rn(d, n);
+    const float q0 = __fmul_rn(d, y);
+    const float r = __fmaf_rn(-q0, n, d);
+    return __fmaf_rn(r, y, q0);
+}
+
 constexpr int CTR_TPB = 64;
 __global__ __launch_bounds__(CTR_TPB) void k_centers(const int* __restrict__ cluster_id, const float* __restrict__ off_xyz,
                                                     const int* __restrict__ clt_seg, const int* __restrict__ seg_off,
@@ -530,18 +565,24 @@ __global__ __launch_bounds__(CTR_TPB) void k_centers(const int* __restrict__ clu
             __syncthreads();
             if (lane < 3) {
                 const float* v = s_xyz[lane];
+                // M += (v - M) / N with the quotient computed as reciprocal + one FMA correction step: bit-identical to
+                // the IEEE division (Markstein; oracle/fastdiv_check.c) but 3 dependent operations instead of ~12 on
+                // the serial chain.  The reciprocals do not depend on M, so they are issued ahead of the chain.
                 int k = 0;
                 for (; k + 4 <= cnt; k += 4) {
-                    const float v0 = v[k], v1 = v[k + 1], v2 = v[k + 2], v3 = v[k + 3];
-                    m = __fadd_rn(m, __fdiv_rn(__fsub_rn(v0, m), (float)(N + 1)));
-                    m = __fadd_rn(m, __fdiv_rn(__fsub_rn(v1, m), (float)(N + 2)));
-                    m = __fadd_rn(m, __fdiv_rn(__fsub_rn(v2, m), (float)(N + 3)));
-                    m = __fadd_rn(m, __fdiv_rn(__fsub_rn(v3, m), (float)(N + 4)));
+                    const float n0 = (float)(N + 1), n1 = (float)(N + 2), n2 = (float)(N + 3), n3 = (float)(N + 4);
+                    const float y0 = __fdiv_rn(1.0f, n0), y1 = __fdiv_rn(1.0f, n1), y2 = __fdiv_rn(1.0f, n2),
+                                y3 = __fdiv_rn(1.0f, n3);
+                    m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k], m), n0, y0));
+                    m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k + 1], m), n1, y1));
+                    m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k + 2], m), n2, y2));
+                    m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k + 3], m), n3, y3));
                     N += 4;
                 }
                 for (; k < cnt; ++k) {
                     ++N;
-                    m = __fadd_rn(m, __fdiv_rn(__fsub_rn(v[k], m), (float)N));
+                    const float fn = (float)N;
+                    m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k], m), fn, __fdiv_rn(1.0f, fn)));
                 }
             } else {
                 N += cnt;
@@ -566,6 +607,7 @@ struct Workspace {
     unsigned long long* hkeys;
     float4 *spt, *cand;
     unsigned hcap;
+    size_t zero_end, ff_end, big_end;  // ends of the three fill blocks (byte offsets in the workspace)
 };
 
 unsigned hash_capacity(int n) {
@@ -577,10 +619,22 @@ unsigned hash_capacity(int n) {
 size_t carve(Carver& cv, Workspace& w, int n, int n_seg, int general) {
     const size_t N = (size_t)(n > 0 ? n : 1);
     w.hcap = hash_capacity(n);
-    w.hkeys = cv.take<unsigned long long>(w.hcap);
+    // zero-filled block (one memset): scalars | hcount | hcursor | size | fsize
+    w.scalars = cv.take<int>(64);
     w.hcount = cv.take<int>(w.hcap);
-    w.hstart = cv.take<int>(w.hcap);
     w.hcursor = cv.take<int>(w.hcap);
+    w.size = cv.take<int>(N);
+    w.fsize = cv.take<int>(N);
+    w.zero_end = cv.off;
+    // 0xff-filled block (one memset): hkeys (EMPTY) | last_assigned (-1)
+    w.hkeys = cv.take<unsigned long long>(w.hcap);
+    w.last_assigned = cv.take<int>((size_t)n_seg + 1);
+    w.ff_end = cv.off;
+    // 0x7f-filled block (one memset): cell_rep (BIG) | semseed (BIG)
+    w.cell_rep = cv.take<int>(w.hcap);
+    w.semseed = cv.take<int>(general ? 18 * N : 1);
+    w.big_end = cv.off;
+    w.hstart = cv.take<int>(w.hcap);
     w.spt = cv.take<float4>(N);
     w.cand = cv.take<float4>(N);
     w.seg_off = cv.take<int>((size_t)n_seg + 1);
@@ -588,24 +642,18 @@ size_t carve(Carver& cv, Workspace& w, int n, int n_seg, int general) {
     w.slot_of_pt = cv.take<int>(N);
     w.sseg = cv.take<int>(N);
     w.sslot = cv.take<int>(N);
-    w.cell_rep = cv.take<int>(w.hcap);
     w.parent = cv.take<int>(N);
     w.lab = cv.take<int>(N);
     w.root = cv.take<int>(N);
-    w.semseed = cv.take<int>(general ? 18 * N : 1);
-    w.size = cv.take<int>(N);
     w.keep = cv.take<int>(N);
     w.newid = cv.take<int>(N);
     w.lab2 = cv.take<int>(N);
     w.clt_seg = cv.take<int>(N);
-    w.last_assigned = cv.take<int>((size_t)n_seg + 1);
-    w.fsize = cv.take<int>(N);
     w.noise_flag = cv.take<int>(N);
     w.noise_pos = cv.take<int>(N);
     w.noise_list = cv.take<int>(N);
     w.mstart_tmp = cv.take<int>(N + 1);
     w.scan_tmp = cv.take<int>(scan_tmp_ints((long long)(w.hcap > N ? w.hcap : N)));
-    w.scalars = cv.take<int>(16);
     return align_up(cv.off, 256);
 }
 
@@ -653,15 +701,15 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
     int* n_noise = w.scalars + 2;
     int* total_assigned = w.scalars + 3;
 
-    PBN_HIP_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int) * 16, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(w.hkeys, 0xff, sizeof(unsigned long long) * w.hcap, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(w.hcount, 0, sizeof(int) * w.hcap, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(w.hcursor, 0, sizeof(int) * w.hcap, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(w.cell_rep, 0x7f, sizeof(int) * w.hcap, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(w.size, 0, sizeof(int) * (size_t)n, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(w.fsize, 0, sizeof(int) * (size_t)n, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(w.last_assigned, 0xff, sizeof(int) * ((size_t)n_seg + 1), stream));
-    if (general) PBN_HIP_CHECK(hipMemsetAsync(w.semseed, 0x7f, sizeof(int) * 18 * (size_t)n, stream));
+    {   // three fills cover every array that needs an initial value (see carve)
+        char* base = (char*)workspace;
+        char* z0 = (char*)w.scalars;
+        char* f0 = (char*)w.hkeys;
+        char* b0 = (char*)w.cell_rep;
+        PBN_HIP_CHECK(hipMemsetAsync(z0, 0, (size_t)(base + w.zero_end - z0), stream));
+        PBN_HIP_CHECK(hipMemsetAsync(f0, 0xff, (size_t)(base + w.ff_end - f0), stream));
+        PBN_HIP_CHECK(hipMemsetAsync(b0, 0x7f, (size_t)(base + w.big_end - b0), stream));
+    }
 
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(64), 0, stream, seg_len, n_seg, n, w.seg_off, status);
     hipLaunchKernelGGL(k_cell_insert, dim3(nb), dim3(TPB), 0, stream, off_xyz, sem, w.seg_off, n_seg, n, inv_cell,
@@ -674,7 +722,10 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
                        w.hstart, w.hcount, den);
     hipLaunchKernelGGL(k_tag_hp, dim3(nb), dim3(TPB), 0, stream, w.spt, n, den, min_pts, w.parent, w.lab, w.sslot, w.cell_rep);
     hipLaunchKernelGGL(k_union, dim3(nb), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
-                       w.hstart, w.hcount, w.parent, w.cell_rep);
+                       w.hstart, w.hcount, w.parent, w.cell_rep, w.sslot, 0);
+    hipLaunchKernelGGL(k_compress, dim3(nb), dim3(TPB), 0, stream, w.spt, n, w.parent);
+    hipLaunchKernelGGL(k_union, dim3(nb), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+                       w.hstart, w.hcount, w.parent, w.cell_rep, w.sslot, 1);
     hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, stream, w.spt, n, w.parent, sem, general, w.semseed, w.lab);
     hipLaunchKernelGGL(k_copy_i32, dim3(nb), dim3(TPB), 0, stream, w.lab, w.root, n);
     if (general)

@@ -79,3 +79,13 @@ def test_get_iou_oracle():
             inter = int((sel == i).sum())
             want = np.float32(np.float32(inter) / (np.float64(np.float32(len(sel) + int(pointnum[i]) - inter)) + 1e-5))
             assert iou[p, i] == want
+
+
+def test_exact_fast_division_evidence():
+    """k_centers replaces the IEEE division on its serial critical path by a reciprocal + FMA correction; the C check
+    compares it bit for bit with the IEEE quotient (reduced range here; the full run is 640 M comparisons)."""
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(here, "oracle"), "fastdiv_check"])
+    out = subprocess.run([os.path.join(here, "oracle", "fastdiv_check"), "30000", "120"], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout
