@@ -509,15 +509,10 @@ __global__ __launch_bounds__(TPB) void k_noise_nn(const int* __restrict__ noise_
     if (id >= 0) atomicAdd(&fsize[id], 1);
 }
 
-// a16 + members CSR: one 64-lane workgroup per final cluster walks its segment in index order.  Each 64-point chunk
-// is compacted (ballot prefix) into LDS; lanes 0..2 then advance the sequential running mean M += (p - M)/N
-// (binary_cuda_functions.cu:237-239) of x, y, z -- three independent dependency chains in one instruction stream, the
-// IEEE division being the critical path that bit-exactness imposes.  The next chunk's loads are issued before the chain.
-// RN(d / n) for an integer-valued n < 2^24 - 1 given y = RN(1/n); falls back to the IEEE division outside the range
-// where the correction step is exact (tiny, huge or non-finite d).
+// RN(d / n) for an integer-valued n < 2^24 - 1 given y = RN(1/n): reciprocal multiply + one FMA correction step
+// (Markstein; bit-for-bit evidence in oracle/fastdiv_check.c).  Exact when no intermediate leaves the normal range,
+// which k_centers guarantees by a per-chunk magnitude check (it falls back to the IEEE division otherwise).
 __device__ __forceinline__ float exact_quotient(float d, float n, float y) {
-    const float ad = fabsf(d);
-    if (!(ad >= 1e-30f && ad <= 1e30f)) return __fdiv_rn(d, n);
     const float q0 = __fmul_rn(d, y);
     const float r = __fmaf_rn(-q0, n, d);
     return __fmaf_rn(r, y, q0);
@@ -529,7 +524,13 @@ __global__ __launch_bounds__(CTR_TPB) void k_centers(const int* __restrict__ clu
                                                     const int* __restrict__ n_clusters_total,
                                                     const int* __restrict__ member_start, int* __restrict__ member_idx,
                                                     float* __restrict__ centers) {
+    // a16 + members CSR: one 64-lane workgroup per final cluster walks its segment in index order.  Each 64-point
+    // chunk is compacted (ballot prefix) into LDS; lanes 0..2 then advance the sequential running mean
+    // M += (p - M)/N (binary_cuda_functions.cu:237-239) of x, y, z.  A single wave is issue-bound, so the chain is kept
+    // to five instructions per member: the 64 reciprocals 1/N of a chunk are computed by all lanes at once and the
+    // quotient is a multiply + two FMAs (exact, see exact_quotient).  The next chunk's loads are issued before the chain.
     __shared__ float s_xyz[3][CTR_TPB];
+    __shared__ float s_rcp[CTR_TPB];
     const int lane = threadIdx.x;
     const int C = *n_clusters_total;
     for (int c = blockIdx.x; c < C; c += gridDim.x) {
@@ -557,36 +558,38 @@ __global__ __launch_bounds__(CTR_TPB) void k_centers(const int* __restrict__ clu
             const int cnt = __popcll(mask);
             if (cnt == 0) continue;
             const int rank = __popcll(mask & ((1ULL << lane) - 1ULL));
+            // magnitudes for which the correction-step quotient is provably exact: 0 or [1e-20, 1e20]
+            const float ax = fabsf(px), ay = fabsf(py), az = fabsf(pz);
+            const bool ok = !hit || ((ax == 0.f || (ax >= 1e-20f && ax <= 1e20f)) && (ay == 0.f || (ay >= 1e-20f && ay <= 1e20f)) &&
+                                     (az == 0.f || (az >= 1e-20f && az <= 1e20f)));
+            const bool fast = __all(ok);
             if (hit) {
                 s_xyz[0][rank] = px; s_xyz[1][rank] = py; s_xyz[2][rank] = pz;
                 if (member_idx) member_idx[wpos + rank] = base + lane;
             }
+            s_rcp[lane] = __fdiv_rn(1.0f, (float)(N + 1 + lane));  // RN(1/n) for the next 64 member counts, all lanes at once
             wpos += cnt;
             __syncthreads();
             if (lane < 3) {
                 const float* v = s_xyz[lane];
-                // M += (v - M) / N with the quotient computed as reciprocal + one FMA correction step: bit-identical to
-                // the IEEE division (Markstein; oracle/fastdiv_check.c) but 3 dependent operations instead of ~12 on
-                // the serial chain.  The reciprocals do not depend on M, so they are issued ahead of the chain.
-                int k = 0;
-                for (; k + 4 <= cnt; k += 4) {
-                    const float n0 = (float)(N + 1), n1 = (float)(N + 2), n2 = (float)(N + 3), n3 = (float)(N + 4);
-                    const float y0 = __fdiv_rn(1.0f, n0), y1 = __fdiv_rn(1.0f, n1), y2 = __fdiv_rn(1.0f, n2),
-                                y3 = __fdiv_rn(1.0f, n3);
-                    m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k], m), n0, y0));
-                    m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k + 1], m), n1, y1));
-                    m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k + 2], m), n2, y2));
-                    m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k + 3], m), n3, y3));
-                    N += 4;
+                if (fast) {
+                    int k = 0;
+                    for (; k + 4 <= cnt; k += 4) {
+                        const float v0 = v[k], v1 = v[k + 1], v2 = v[k + 2], v3 = v[k + 3];
+                        const float y0 = s_rcp[k], y1 = s_rcp[k + 1], y2 = s_rcp[k + 2], y3 = s_rcp[k + 3];
+                        const float n0 = (float)(N + k + 1);
+                        m = __fadd_rn(m, exact_quotient(__fsub_rn(v0, m), n0, y0));
+                        m = __fadd_rn(m, exact_quotient(__fsub_rn(v1, m), n0 + 1.0f, y1));
+                        m = __fadd_rn(m, exact_quotient(__fsub_rn(v2, m), n0 + 2.0f, y2));
+                        m = __fadd_rn(m, exact_quotient(__fsub_rn(v3, m), n0 + 3.0f, y3));
+                    }
+                    for (; k < cnt; ++k)
+                        m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k], m), (float)(N + k + 1), s_rcp[k]));
+                } else {
+                    for (int k = 0; k < cnt; ++k) m = __fadd_rn(m, __fdiv_rn(__fsub_rn(v[k], m), (float)(N + k + 1)));
                 }
-                for (; k < cnt; ++k) {
-                    ++N;
-                    const float fn = (float)N;
-                    m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k], m), fn, __fdiv_rn(1.0f, fn)));
-                }
-            } else {
-                N += cnt;
             }
+            N += cnt;
             __syncthreads();
         }
         if (lane < 3) centers[3 * c + lane] = m;
