@@ -73,7 +73,7 @@ class ConvProbe(object):
             return rows[lout]
         if kind in (3, 4):
             return rows[min(lin, lout)]           # every fine voxel has exactly one parent
-        nbr = cm.kernel_map(1 << lout, 3 if kind == 1 else 5)
+        nbr = cm.kernel_map(1 << lout, 3 if kind == 1 else 5)   # cm: the pyramid the executor ran on
         return int((nbr >= 0).sum().item())
 
     def unet_sink(self, model, plan, rows, cm, esz, op_ms):

@@ -189,8 +189,13 @@ typedef struct {
 } pbn_coords_layout;
 
 size_t pbn_coords_arena_bytes(int n, int want_k5, pbn_coords_layout* layout);
-int pbn_coords_build(const int32_t* coords, int n, int want_k5, int x_fastest, void* arena, size_t arena_bytes,
-                     const pbn_coords_layout* layout, pbn_stream_t stream);
+int pbn_coords_build(const int32_t* coords, const int32_t* n_dev, int n, int want_k5, int x_fastest, void* arena,
+                     size_t arena_bytes, const pbn_coords_layout* layout, pbn_stream_t stream);
+
+/* Z-order keys (batch-major, then bit-interleaved x, y, z) of coordinate rows; rows at or beyond *n_dev get the largest
+ * key.  Sorting rows by this key turns every run of consecutive rows into a compact spatial block: convolution tiles
+ * then drop whole offset groups and their gathers stay inside one XCD's L2. */
+int pbn_morton_keys(const int32_t* coords, const int32_t* n_dev, int n_max, int64_t* keys, pbn_stream_t stream);
 
 /* pbn_unet_forward: executes a static list of fused convolutions -- MinkUNetBase.forward (network/Mink.py:291-354) with
  * eval-mode BatchNorm, ReLU and residual adds folded into the epilogues and skip concatenations written in place.

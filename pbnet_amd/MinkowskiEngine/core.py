@@ -35,18 +35,95 @@ class _Level(object):
     __slots__ = ("stride", "coords", "n", "n_dev", "keys", "vals", "capacity", "parent_row", "child_k", "nbr_down")
 
 
+class _Pyramid(object):
+    """One coordinate order of a lineage, fully expanded by ONE native call (pbn_coords_build): the four coarser levels,
+    the k=3 maps of all levels, the k=5 map of level 1 and the transposed-convolution tables, in one arena with
+    device-resident row counts."""
+    _STRIDES = (1, 2, 4, 8, 16)
+
+    def __init__(self, coords, n_dev, n_cap):
+        lib = N.lib()
+        self.device = coords.device
+        self.layout = N.CoordsLayout()
+        nbytes = lib.pbn_coords_arena_bytes(n_cap, 1, ctypes.byref(self.layout))
+        self.arena = torch.empty(nbytes, dtype=torch.uint8, device=coords.device)
+        rc = lib.pbn_coords_build(N.ptr(coords), None if n_dev is None else N.ptr(n_dev), n_cap, 1, int(CV.X_FASTEST),
+                                  N.ptr(self.arena), nbytes, ctypes.byref(self.layout), N.current_stream())
+        N.check(rc, "pbn_coords_build")
+        self.counts_dev = self.view(self.layout.counts, 5, torch.int32)
+        self.n = None
+
+    def view(self, offset, count, dtype, shape=None):
+        nbytes = count * torch.empty(0, dtype=dtype).element_size()
+        t = self.arena[offset:offset + nbytes].view(dtype)
+        return t if shape is None else t.view(shape)
+
+    def ptr(self, offset):
+        return self.arena.data_ptr() + offset
+
+    def set_counts(self, counts):
+        if counts[0] < 0:
+            raise ValueError("coordinate out of range: batch must be in [0,65534], x/y/z in [-32768,32767]")
+        self.n = [int(c) for c in counts]
+
+    def finalize(self):
+        if self.n is None:
+            self.set_counts(self.counts_dev.tolist())
+
+    def level_index(self, stride):
+        return self._STRIDES.index(stride)
+
+    def coordinates(self, stride):
+        self.finalize()
+        l = self.level_index(stride)
+        return self.view(self.layout.coords[l], self.n[l] * 4, torch.int32, (self.n[l], 4))
+
+    def kernel_map(self, stride, kernel_size):
+        self.finalize()
+        l = self.level_index(stride)
+        if kernel_size == 3:
+            return self.view(self.layout.k3[l], self.n[l] * 27, torch.int32, (self.n[l], 27))
+        assert kernel_size == 5 and stride == 1
+        return self.view(self.layout.k5, self.n[0] * 125, torch.int32, (self.n[0], 125))
+
+    def down_map(self, stride_in):
+        self.finalize()
+        l = self.level_index(stride_in)
+        return self.view(self.layout.nbr_down[l], self.n[l + 1] * 8, torch.int32, (self.n[l + 1], 8))
+
+    def up_map(self, stride_in):
+        self.finalize()
+        l = self.level_index(stride_in) - 1
+        return self.view(self.layout.up[l], self.n[l] * 8, torch.int32, (self.n[l], 8))
+
+    def native_tables(self):
+        self.finalize()
+        L = self.layout
+        return ([self.ptr(L.k3[l]) for l in range(5)], self.ptr(L.k5), [self.ptr(L.nbr_down[l]) for l in range(4)],
+                [self.ptr(L.up[l]) for l in range(4)])
+
+
+class SortedView(object):
+    """The lineage in Morton (Z) order: `perm[p]` = external row at sorted position p, `inv_perm` its inverse."""
+    __slots__ = ("pyramid", "perm", "inv_perm")
+
+
 class CoordinateManager(object):
     """Owns the coordinate sets of one SparseTensor lineage and the kernel maps between them (ME caches both per
     lineage in its coordinate manager, so transposed convolutions land exactly on the encoder's coordinates).
 
-    Construction is ONE native call (pbn_coords_build): de-duplication, the four coarser levels, the k=3 maps of all
-    levels, the k=5 map of level 1 and the transposed-convolution tables, laid out in one arena with device-resident
-    row counts.  The five counts come back in ONE host read the first time a size is needed."""
+    External row order = survivors of the de-duplication in ascending original order (ME semantics).  Two expansions
+    of the lineage exist, each built by one native call and only when asked for:
+      * `plain`  -- maps in the external row order (module-by-module path, training);
+      * `sorted` -- the same lineage in Morton order (fused inference path): a 128-row tile is then a compact spatial
+                    block, so whole kernel offsets drop out of a tile and its gathers stay L2-local.  Coarser levels
+                    inherit the order (parents are numbered by first occurrence).
+    `prepare` selects what is launched up front so that all row counts come back in ONE host read."""
 
     MAX_STRIDE = 16
     _STRIDES = (1, 2, 4, 8, 16)
 
-    def __init__(self, coordinates, build_maps=True):
+    def __init__(self, coordinates, build_maps=True, prepare=None):
         N.require_cuda(coordinates)
         coords = coordinates.to(torch.int32).contiguous()
         assert coords.dim() == 2 and coords.shape[1] == 4, "coordinates must be [N,4] (batch, x, y, z)"
@@ -55,117 +132,134 @@ class CoordinateManager(object):
         n = int(coords.shape[0])
         self.device = dev
         self.n_input = n
-        self.build_maps = build_maps
         self._maps = {}
+        self._plain = None
+        self._sorted = None
         self._final = False
         self.unique_index = self.inverse_mapping = self.is_identity = None
-        self._n = None
-        if build_maps:
-            self._layout = N.CoordsLayout()
-            nbytes = lib.pbn_coords_arena_bytes(n, 1, ctypes.byref(self._layout))
-            self._arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            rc = lib.pbn_coords_build(N.ptr(coords), n, 1, int(CV.X_FASTEST), N.ptr(self._arena), nbytes,
-                                      ctypes.byref(self._layout), N.current_stream())
-            N.check(rc, "pbn_coords_build")
-            self._counts = self._view(self._layout.counts, 5, torch.int32)
-        else:  # de-duplication only (ME.utils.sparse_quantize)
-            cap = lib.pbn_hash_capacity(n)
-            self._keys = torch.empty(cap, dtype=torch.int64, device=dev)
-            self._vals = _i32(cap, dev)
-            self._counts = _i32(1, dev)
-            self._uidx, self._inv = _i32(max(n, 1), dev), _i32(max(n, 1), dev)
-            self._ucoords = torch.empty(max(n, 1), 4, dtype=torch.int32, device=dev)
-            wsb = lib.pbn_coords_workspace_bytes(n)
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            rc = lib.pbn_coords_unique(N.ptr(coords), None, n, N.ptr(self._keys), N.ptr(self._vals), cap,
-                                       N.ptr(self._uidx), N.ptr(self._inv), N.ptr(self._ucoords), N.ptr(self._counts),
-                                       N.ptr(ws), wsb, N.current_stream())
-            N.check(rc, "pbn_coords_unique")
+        self._n1 = None
+        cap = lib.pbn_hash_capacity(n)
+        keys = torch.empty(cap, dtype=torch.int64, device=dev)
+        vals = _i32(cap, dev)
+        self._count = _i32(1, dev)
+        self._uidx, self._inv = _i32(max(n, 1), dev), _i32(max(n, 1), dev)
+        self._ucoords = torch.empty(max(n, 1), 4, dtype=torch.int32, device=dev)
+        wsb = lib.pbn_coords_workspace_bytes(n)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = lib.pbn_coords_unique(N.ptr(coords), None, n, N.ptr(keys), N.ptr(vals), cap, N.ptr(self._uidx),
+                                   N.ptr(self._inv), N.ptr(self._ucoords), N.ptr(self._count), N.ptr(ws), wsb,
+                                   N.current_stream())
+        N.check(rc, "pbn_coords_unique")
+        if prepare is None:
+            prepare = ("plain" if torch.is_grad_enabled() else "sorted") if build_maps else "unique"
+        if prepare == "plain":
+            self._build_plain()
+        elif prepare == "sorted":
+            self._build_sorted()
 
-    def _view(self, offset, count, dtype, shape=None):
-        nbytes = count * torch.empty(0, dtype=dtype).element_size()
-        t = self._arena[offset:offset + nbytes].view(dtype)
-        return t if shape is None else t.view(shape)
+    # -- expansions ---------------------------------------------------------------------------------------------
+    def _build_plain(self):
+        if self._plain is None:
+            self._plain = _Pyramid(self._ucoords, self._count, self.n_input)
+        return self._plain
 
-    def _ptr(self, offset):
-        return self._arena.data_ptr() + offset
+    def _build_sorted(self):
+        if self._sorted is None:
+            n = self.n_input
+            keys = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+            rc = N.lib().pbn_morton_keys(N.ptr(self._ucoords), N.ptr(self._count), n, N.ptr(keys), N.current_stream())
+            N.check(rc, "pbn_morton_keys")
+            perm = torch.sort(keys[:n], stable=True)[1]            # padding rows (beyond the unique count) sort last
+            sv = SortedView()
+            sv.perm = perm
+            sv.pyramid = _Pyramid(self._ucoords[perm].contiguous(), self._count, n)
+            sv.inv_perm = None
+            self._sorted = sv
+        return self._sorted
 
-    # -- sizes ------------------------------------------------------------------------------------------------
     def _finalize(self):
         if self._final:
             return
-        counts = self._counts.tolist()  # the one host synchronisation of this lineage
+        pending = [p for p in (self._plain, self._sorted.pyramid if self._sorted else None) if p is not None and p.n is None]
+        counts = torch.cat([self._count] + [p.counts_dev for p in pending]).tolist()   # the one host read
         if counts[0] < 0:
             raise ValueError("coordinate out of range: batch must be in [0,65534], x/y/z in [-32768,32767]")
-        self._n = [int(c) for c in counts]
-        n1 = self._n[0]
-        if self.build_maps:
-            self.unique_index = self._view(self._layout.unique_index, n1, torch.int32).long()
-            self.inverse_mapping = self._view(self._layout.inverse, self.n_input, torch.int32).long()
-        else:
-            self.unique_index = self._uidx[:n1].long()
-            self.inverse_mapping = self._inv[:self.n_input].long()
+        self._n1 = int(counts[0])
+        for i, p in enumerate(pending):
+            p.set_counts(counts[1 + 5 * i:6 + 5 * i])
+        n1 = self._n1
+        self.unique_index = self._uidx[:n1].long()
+        self.inverse_mapping = self._inv[:self.n_input].long()
         self.is_identity = (n1 == self.n_input)
+        if self._sorted is not None:
+            sv = self._sorted
+            sv.perm = sv.perm[:n1]
+            sv.inv_perm = torch.empty_like(sv.perm)
+            sv.inv_perm[sv.perm] = torch.arange(n1, device=self.device)
         self._final = True
 
-    def _level_index(self, stride):
-        assert self.build_maps, "this coordinate manager was built for de-duplication only"
-        return self._STRIDES.index(stride)
+    def plain(self):
+        self._finalize()
+        if self._plain is None:
+            self._build_plain()
+        self._plain.finalize()
+        return self._plain
 
+    def sorted(self):
+        self._finalize()
+        if self._sorted is None:
+            self._build_sorted()
+            sv = self._sorted
+            sv.pyramid.finalize()
+            sv.perm = sv.perm[:self._n1]
+            sv.inv_perm = torch.empty_like(sv.perm)
+            sv.inv_perm[sv.perm] = torch.arange(self._n1, device=self.device)
+        return self._sorted
+
+    # -- sizes ------------------------------------------------------------------------------------------------
     def num_rows(self, stride):
         self._finalize()
-        return self._n[self._STRIDES.index(stride)] if self.build_maps else self._n[0]
+        if stride == 1:
+            return self._n1
+        pyr = self._plain if self._plain is not None else (self._sorted.pyramid if self._sorted else self.plain())
+        pyr.finalize()
+        return pyr.n[self._STRIDES.index(stride)]
 
     def row_counts(self):
-        self._finalize()
-        return list(self._n)
+        return [self.num_rows(s) for s in self._STRIDES]
 
     def coordinates(self, stride):
         self._finalize()
-        if not self.build_maps:
-            return self._ucoords[:self._n[0]]
-        l = self._level_index(stride)
-        return self._view(self._layout.coords[l], self._n[l] * 4, torch.int32, (self._n[l], 4))
+        if stride == 1:
+            return self._ucoords[:self._n1]
+        return self.plain().coordinates(stride)
 
-    # -- kernel maps (views into the arena; rows beyond the level's count are never touched) ---------------------
+    # -- kernel maps in the external row order --------------------------------------------------------------------
     def kernel_map(self, stride, kernel_size):
         """nbr[n(stride), K^3] for a stride-1 (in the tensor-stride sense) convolution of odd kernel size."""
-        self._finalize()
-        l = self._level_index(stride)
-        if kernel_size == 3:
-            return self._view(self._layout.k3[l], self._n[l] * 27, torch.int32, (self._n[l], 27))
-        if kernel_size == 5 and stride == 1:
-            return self._view(self._layout.k5, self._n[0] * 125, torch.int32, (self._n[0], 125))
+        pyr = self.plain()
+        if kernel_size == 3 or (kernel_size == 5 and stride == 1):
+            return pyr.kernel_map(stride, kernel_size)
         key = ("k", stride, kernel_size)
         if key not in self._maps:
-            n = self._n[l]
+            l = pyr.level_index(stride)
+            n = pyr.n[l]
+            L = pyr.layout
             nbr = torch.empty(max(n, 1), kernel_size ** 3, dtype=torch.int32, device=self.device)
-            rc = N.lib().pbn_kernel_map_cube(N.c_vp(self._ptr(self._layout.coords[l])), None, n, kernel_size, stride,
-                                             int(CV.X_FASTEST), N.c_vp(self._ptr(self._layout.keys[l])),
-                                             N.c_vp(self._ptr(self._layout.vals[l])), self._layout.capacity[l],
-                                             N.ptr(nbr), N.current_stream())
+            rc = N.lib().pbn_kernel_map_cube(N.c_vp(pyr.ptr(L.coords[l])), None, n, kernel_size, stride,
+                                             int(CV.X_FASTEST), N.c_vp(pyr.ptr(L.keys[l])), N.c_vp(pyr.ptr(L.vals[l])),
+                                             L.capacity[l], N.ptr(nbr), N.current_stream())
             N.check(rc, "pbn_kernel_map_cube")
             self._maps[key] = nbr[:n]
         return self._maps[key]
 
     def down_map(self, stride_in):
         """k=2,s=2 convolution stride_in -> 2*stride_in: nbr_down[n_coarse, 8] child rows."""
-        self._finalize()
-        l = self._level_index(stride_in)
-        return self._view(self._layout.nbr_down[l], self._n[l + 1] * 8, torch.int32, (self._n[l + 1], 8))
+        return self.plain().down_map(stride_in)
 
     def up_map(self, stride_in):
         """Transposed k=2,s=2 convolution stride_in -> stride_in/2: nbr_up[n_fine, 8]."""
-        self._finalize()
-        l = self._level_index(stride_in) - 1
-        return self._view(self._layout.up[l], self._n[l] * 8, torch.int32, (self._n[l], 8))
-
-    def native_tables(self):
-        """Raw device addresses for the native U-Net executor: (k3[5], k5, down[4], up[4])."""
-        self._finalize()
-        L = self._layout
-        return ([self._ptr(L.k3[l]) for l in range(5)], self._ptr(L.k5), [self._ptr(L.nbr_down[l]) for l in range(4)],
-                [self._ptr(L.up[l]) for l in range(4)])
+        return self.plain().up_map(stride_in)
 
 
 class SparseTensor(object):

@@ -40,7 +40,7 @@ def sparse_quantize(coordinates, features=None, labels=None, ignore_label=-100, 
         c = torch.floor(c.double() / quantization_size)
     q = c.to(torch.int32).to(device)
     c4 = torch.cat([torch.zeros(q.shape[0], 1, dtype=torch.int32, device=q.device), q], 1)
-    cm = CoordinateManager(c4, build_maps=False)
+    cm = CoordinateManager(c4, prepare="unique")
     cm.num_rows(1)
     index, inverse = cm.unique_index, cm.inverse_mapping
     if return_maps_only:

@@ -68,7 +68,8 @@ SIGNATURES = {
     "pbn_segment_pool": (c_int, [c_vp, c_int, c_int, c_int, c_i32p, c_int, c_f32p, c_f32p, c_vp]),
     "pbn_kernel_map_cube": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_coords_arena_bytes": (c_size, [c_int, c_int, ctypes.POINTER(CoordsLayout)]),
-    "pbn_coords_build": (c_int, [c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(CoordsLayout), c_vp]),
+    "pbn_coords_build": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(CoordsLayout), c_vp]),
+    "pbn_morton_keys": (c_int, [c_i32p, c_i32p, c_int, c_vp, c_vp]),
     "pbn_unet_arena_bytes": (c_size, [ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32), c_int,
                                       ctypes.POINTER(c_i64)]),
     "pbn_unet_forward": (c_int, [ctypes.POINTER(UnetOp), c_int, ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32),

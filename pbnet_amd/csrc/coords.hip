@@ -341,3 +341,40 @@ extern "C" int pbn_kernel_map_cube(const int32_t* out_coords, const int32_t* n_o
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
+
+
+// ---- Morton (Z-order) keys: batch-major, then bit-interleaved (x, y, z): rows sorted by this key make every run of
+// consecutive rows a compact spatial block, which is what the convolution tiles and their L2 locality want -------------
+namespace pbn {
+namespace {
+__device__ __forceinline__ unsigned long long spread3(unsigned v) {  // 16 bits -> every third bit of 48
+    unsigned long long x = v & 0xffffu;
+    x = (x | (x << 32)) & 0x00ff00000000ffffULL;
+    x = (x | (x << 16)) & 0x00ff0000ff0000ffULL;
+    x = (x | (x << 8)) & 0xf00f00f00f00f00fULL;
+    x = (x | (x << 4)) & 0x30c30c30c30c30c3ULL;
+    x = (x | (x << 2)) & 0x9249249249249249ULL;
+    return x;
+}
+__global__ __launch_bounds__(TPB) void k_morton_keys(const int* __restrict__ coords, const int* n_dev, int n_max,
+                                                    long long* __restrict__ keys) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n_max) return;
+    if (i >= real_n(n_dev, n_max)) { keys[i] = 0x7fffffffffffffffLL; return; }  // padding rows sort to the end
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    const unsigned long long m = spread3((unsigned)(c.y + 32768)) | (spread3((unsigned)(c.z + 32768)) << 1) |
+                                 (spread3((unsigned)(c.w + 32768)) << 2);
+    keys[i] = (long long)((((unsigned long long)(unsigned)c.x & 0x7fffULL) << 48) | (m & 0xffffffffffffULL));
+}
+}  // namespace
+}  // namespace pbn
+
+extern "C" int pbn_morton_keys(const int32_t* coords, const int32_t* n_dev, int n_max, int64_t* keys, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_max < 0) return PBN_ERR_ARG;
+    if (n_max == 0) return PBN_OK;
+    if (!coords || !keys) return PBN_ERR_ARG;
+    hipLaunchKernelGGL(k_morton_keys, dim3(cdiv(n_max, TPB)), dim3(TPB), 0, stream, coords, n_dev, n_max, (long long*)keys);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}

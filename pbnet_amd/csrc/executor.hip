@@ -40,8 +40,8 @@ extern "C" size_t pbn_coords_arena_bytes(int n, int want_k5, pbn_coords_layout* 
     return off;
 }
 
-extern "C" int pbn_coords_build(const int32_t* coords, int n, int want_k5, int x_fastest, void* arena, size_t arena_bytes,
-                                const pbn_coords_layout* L, pbn_stream_t stream) {
+extern "C" int pbn_coords_build(const int32_t* coords, const int32_t* n_dev, int n, int want_k5, int x_fastest, void* arena,
+                                size_t arena_bytes, const pbn_coords_layout* L, pbn_stream_t stream) {
     if (n < 0 || !arena || !L) return PBN_ERR_ARG;
     pbn_coords_layout chk;
     if (pbn_coords_arena_bytes(n, want_k5, &chk) > arena_bytes) return PBN_ERR_WORKSPACE;
@@ -50,7 +50,7 @@ extern "C" int pbn_coords_build(const int32_t* coords, int n, int want_k5, int x
     int32_t* counts = I(L->counts);
     void* ws = A + L->workspace;
     const size_t wsb = (size_t)L->workspace_bytes;
-    int rc = pbn_coords_unique(coords, nullptr, n, (uint64_t*)(A + L->keys[0]), I(L->vals[0]), L->capacity[0],
+    int rc = pbn_coords_unique(coords, n_dev, n, (uint64_t*)(A + L->keys[0]), I(L->vals[0]), L->capacity[0],
                                I(L->unique_index), I(L->inverse), I(L->coords[0]), counts + 0, ws, wsb, stream);
     if (rc != PBN_OK) return rc;
     for (int l = 0; l < 4; ++l) {

@@ -41,6 +41,7 @@ _UP_BN = ("bntr4", "bntr5", "bntr6", "bntr7")
 
 class MinkUNet(nn.Module):
     FUSE_EVAL = True
+    MORTON = True           # fused path runs the lineage in Z-order (bit-identical outputs, better tiles)
     OP_TIMING_SINK = None   # callable(model, plan, rows, cm, esz, op_ms) installed by bench.py's roofline probe
 
     def __init__(self, in_channels, out_channels, D=3, arch="MinkUNet34C"):
@@ -220,22 +221,24 @@ class MinkUNet(nn.Module):
         from ..MinkowskiEngine.conv import _DT, _workspace
         cm = x.coordinate_manager
         assert x.tensor_stride == 1
+        sv = cm.sorted() if self.MORTON else None      # the lineage in Z-order: compact tiles, L2-local gathers
+        pyr = sv.pyramid if sv is not None else cm.plain()
         feats = x.F
         dt, dev = feats.dtype, feats.device
         plan = self._plan(dt)
         cin_p = plan["cin_p"]
-        if feats.shape[1] < cin_p or feats.stride(1) != 1 or (feats.stride(0) * feats.element_size()) % 16 \
-                or feats.data_ptr() % 16:
+        if sv is not None or feats.shape[1] < cin_p or feats.stride(1) != 1 \
+                or (feats.stride(0) * feats.element_size()) % 16 or feats.data_ptr() % 16:
             padded = torch.zeros(feats.shape[0], cin_p, dtype=dt, device=dev)
-            padded[:, :feats.shape[1]] = feats
+            padded[:, :feats.shape[1]] = feats if sv is None else feats[sv.perm]
             feats = padded
-        rows = cm.row_counts()
+        rows = list(pyr.n)
         n_rows = (ctypes.c_int32 * 5)(*rows)
         offs = (ctypes.c_int64 * plan["n_bufs"])()
         lib = N.lib()
         nbytes = lib.pbn_unet_arena_bytes(plan["bufs"], plan["n_bufs"], n_rows, _DT[dt], offs)
         arena = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-        k3, k5, down, up = cm.native_tables()
+        k3, k5, down, up = pyr.native_tables()
         vp = ctypes.c_void_p
         ws = _workspace(dev)
         args = (plan["ops"], plan["n_ops"], plan["bufs"], plan["n_bufs"], n_rows, vp(feats.data_ptr()), feats.stride(0),
@@ -246,11 +249,13 @@ class MinkUNet(nn.Module):
         else:  # bench.py's roofline probe: per-op HIP-event durations (synchronises)
             op_ms = (ctypes.c_float * plan["n_ops"])()
             rc = lib.pbn_unet_forward_timed(*(args + (op_ms,)))
-            MinkUNet.OP_TIMING_SINK(self, plan, rows, cm, feats.element_size(), list(op_ms))
+            MinkUNet.OP_TIMING_SINK(self, plan, rows, pyr, feats.element_size(), list(op_ms))
         N.check(rc, "pbn_unet_forward")
         o = offs[plan["out_buf"]]
         width = plan["out_width"]
         out = arena[o:o + rows[0] * width * feats.element_size()].view(dt).view(rows[0], width)
+        if sv is not None:
+            out = out[sv.inv_perm]                         # back to the external row order
         cout = self.final_sematic.kernel.shape[-1]
         return ME.SparseTensor(out if width == cout else out[:, :cout], coordinate_manager=cm, tensor_stride=1)
 
