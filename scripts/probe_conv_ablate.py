@@ -9,11 +9,13 @@ dev = "cuda:0"
 batch, _, _ = synth.make_val_batch(seed=2, copies=1)
 coords = torch.from_numpy(batch["xyz_voxel"]).to(dev)
 cm = ME.CoordinateManager(coords)
+SORTED = os.environ.get("PBN_PROBE_SORTED", "0") == "1"
+pyr = cm.sorted().pyramid if SORTED else cm.plain()
 torch.manual_seed(0)
 def run(level, cin, cout, k=3, rw=0):
     stride = 1 << level
-    n = cm.num_rows(stride)
-    nbr = cm.kernel_map(stride, k)
+    n = pyr.n[level]
+    nbr = pyr.kernel_map(stride, k)
     conv = ME.MinkowskiConvolution(cin, cout, kernel_size=k, dimension=3).to(dev)
     x = torch.randn(n, cin, device=dev).to(torch.bfloat16)
     packed = conv._cache.get(conv.kernel, torch.bfloat16)
@@ -25,9 +27,10 @@ def run(level, cin, cout, k=3, rw=0):
     pairs = int((nbr >= 0).sum().item())
     # fragment-level fill: fraction of (16-row fragment, offset) pairs with at least one neighbour
     nb16 = (nbr[: n // 16 * 16].view(-1, 16, nbr.shape[1]) >= 0).any(1).float().mean().item()
+    nb128 = (nbr[: n // 128 * 128].view(-1, 128, nbr.shape[1]) >= 0).any(1).float().mean().item()
     t = e0.elapsed_time(e1) / 10 * 1e3
-    print("dbg=%s level=%d rows=%d %d->%d K=%d rw=%d: %.1f us  (pairs/row %.2f, fragment fill %.2f, %.1f TFLOP/s real)" % (
-        os.environ.get("PBN_CONV_DBG", "0"), level, n, cin, cout, k ** 3, rw, t, pairs / n, nb16, 2 * pairs * cin * cout / t / 1e6))
+    print("dbg=%s level=%d rows=%d %d->%d K=%d rw=%d: %.1f us  (pairs/row %.2f, fill16 %.2f, fill128 %.2f, %.1f TFLOP/s real) sorted=%s" % (
+        os.environ.get("PBN_CONV_DBG", "0"), level, n, cin, cout, k ** 3, rw, t, pairs / n, nb16, nb128, 2 * pairs * cin * cout / t / 1e6, SORTED))
 run(0, 96, 96)
 run(0, 96, 96, rw=16)
 run(1, 96, 96)

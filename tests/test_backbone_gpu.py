@@ -160,9 +160,14 @@ def test_unet_matches_golden_and_oracle(arch, golden_dir):
         m.FUSE_EVAL = False
         unfused = m(x).F.cpu()
         m.FUSE_EVAL = True
-    assert torch.equal(fused, fused_py), "native executor and Python-issued fused path must be bit-identical"
+    # Z-order changes which tiles split their reduction (split-K slices), not what is summed: same values up to fp32
+    # re-association; with the external row order the native executor is bit-identical to the Python-issued plan
+    assert (fused - fused_py).abs().max().item() <= 1e-5 * max(1.0, fused_py.abs().max().item())
     with torch.no_grad():
-        pass
+        type(m).MORTON = False
+        fused_plain = m(x).F.cpu()
+        type(m).MORTON = True
+    assert torch.equal(fused_plain, fused_py), "native executor and Python-issued fused path must be bit-identical"
     scale = max(1.0, want_eval.abs().max().item())
     assert (fused - want_eval).abs().max().item() <= TOL * scale, "fused eval path"
     assert (unfused - want_eval).abs().max().item() <= TOL * scale, "module eval path"
