@@ -477,6 +477,7 @@ int launch_nt(const ConvArgs& a, float* ws, size_t wsb, hipStream_t stream) {
 
 template <typename T>
 int launch_t(const ConvArgs& a, int rows_per_wave, float* ws, size_t wsb, hipStream_t stream) {
+    if (rows_per_wave == 64) return launch_nt<T, 64>(a, ws, wsb, stream);
     if (rows_per_wave == 32) return launch_nt<T, 32>(a, ws, wsb, stream);
     return launch_nt<T, 16>(a, ws, wsb, stream);
 }
@@ -523,7 +524,7 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, const int32_t*
     a.dbg = dbg_env;
     float* ws = reinterpret_cast<float*>(workspace);
     if (((uintptr_t)workspace) & 15) ws = nullptr;
-    if (rows_per_wave != 16 && rows_per_wave != 32) rows_per_wave = (n_out >= 64 * 1024) ? 32 : 16;
+    if (rows_per_wave != 16 && rows_per_wave != 32 && rows_per_wave != 64) rows_per_wave = (n_out >= 8 * 1024) ? 32 : 16;
     switch (dtype) {
         case PBN_F32: return launch_t<float>(a, rows_per_wave, ws, workspace_bytes, stream);
         case PBN_BF16: return launch_t<__hip_bfloat16>(a, rows_per_wave, ws, workspace_bytes, stream);

@@ -31,9 +31,8 @@ def run(level, cin, cout, k=3, rw=0):
     t = e0.elapsed_time(e1) / 10 * 1e3
     print("dbg=%s level=%d rows=%d %d->%d K=%d rw=%d: %.1f us  (pairs/row %.2f, fill16 %.2f, fill128 %.2f, %.1f TFLOP/s real) sorted=%s" % (
         os.environ.get("PBN_CONV_DBG", "0"), level, n, cin, cout, k ** 3, rw, t, pairs / n, nb16, nb128, 2 * pairs * cin * cout / t / 1e6, SORTED))
-run(0, 96, 96)
-run(0, 96, 96, rw=16)
-run(1, 96, 96)
-run(2, 128, 128)
-run(3, 256, 256)
-run(4, 256, 256)
+RWS = [int(v) for v in os.environ.get("PBN_PROBE_RWS", "16,32").split(",")]
+CASES = {"0": (0, 96, 96), "1": (1, 96, 96), "2": (2, 128, 128), "3": (3, 256, 256), "3n": (3, 128, 128), "4": (4, 256, 256)}
+for rw in RWS:
+    for c in os.environ.get("PBN_PROBE_CASES", "0,1,2,3,3n,4").split(","):
+        run(*CASES[c], rw=rw)
