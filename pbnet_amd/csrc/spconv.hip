@@ -31,6 +31,8 @@ namespace pbn {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -60,21 +62,21 @@ template <> struct Tr<__hip_bfloat16> { static constexpr int ELEMS = 8; };
 template <> struct Tr<__half> { static constexpr int ELEMS = 8; };
 
 template <typename T>
-__device__ __forceinline__ void mfma_step(const uint4& w, const uint4& x, f32x4& acc);
+__device__ __forceinline__ void mfma_step(const u32x4& w, const u32x4& x, f32x4& acc);
 
 template <>
-__device__ __forceinline__ void mfma_step<float>(const uint4& w, const uint4& x, f32x4& acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
+__device__ __forceinline__ void mfma_step<float>(const u32x4& w, const u32x4& x, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[0]), __uint_as_float(x[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[1]), __uint_as_float(x[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[2]), __uint_as_float(x[2]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[3]), __uint_as_float(x[3]), acc, 0, 0, 0);
 }
 template <>
-__device__ __forceinline__ void mfma_step<__hip_bfloat16>(const uint4& w, const uint4& x, f32x4& acc) {
+__device__ __forceinline__ void mfma_step<__hip_bfloat16>(const u32x4& w, const u32x4& x, f32x4& acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
 }
 template <>
-__device__ __forceinline__ void mfma_step<__half>(const uint4& w, const uint4& x, f32x4& acc) {
+__device__ __forceinline__ void mfma_step<__half>(const u32x4& w, const u32x4& x, f32x4& acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
 }
 
@@ -125,28 +127,42 @@ __device__ __forceinline__ int xcd_tile(int b, int nt) {  // contiguous tile ran
 
 constexpr int CONV_TPB = 256;
 
-constexpr int CGMAX = 4;  // channel chunks (steps) per barrier group
+constexpr int CGMAX = 4;  // channel chunks (steps) per group
+
+#define PBN_LDS_ADDR(p) ((unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)(p)))
 
 // Reduction axis: STEP s = 4 x 16-byte vectors of the flattened (offset, channel) axis; GROUP = cg consecutive steps
 // of ONE kernel offset (cg = largest divisor <= 4 of the steps per offset; 1 when an offset is narrower than a step).
-// Per group: one barrier pair to swap the weight tile in LDS; inside a group the waves run free, each prefetching
-// its next gather while the matrix cores work on the current one.
-template <typename T, int RW, int NT>
+//
+// Main loop, per group (one barrier):
+//   * the group's weight tile (cg x NT KiB, fragment order) is copied global -> LDS by the DMA path
+//     (buffer_load ... lds: no staging registers, no ds_write pass) into one of two ring slots, one group ahead;
+//   * a lane's gather operands live in ONE register set: as soon as the matrix cores have consumed chunk c of the
+//     current group, the same registers are refilled with chunk c of the next group, so every gather has a full
+//     group of MFMA work to land behind;
+//   * a wave owns NF 16-row fragments: each weight fragment read from LDS feeds NF MFMAs; fragments are read one
+//     chunk ahead of the MFMAs that use them.
+// Every vector-memory instruction of the loop is issued from inline asm with hand-counted s_waitcnt vmcnt(N): loads
+// complete in issue order, so "the DMA of this group has landed" and "chunk c has landed" are fixed counts of the
+// loads issued after them -- the barrier never waits for the gathers behind the DMA, an MFMA never waits for a DMA.
+// (hipcc's own wait-count insertion is conservative across the loop's branches and drains the queue.)
+template <typename T, int NF, int NT>
 __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     static_assert(Tr<T>::ELEMS * sizeof(T) == 16, "one gather vector is 16 bytes");
+    constexpr int RW = NF * 16;
     constexpr int TM = 4 * RW;
-    constexpr int NF = RW / 16;
     constexpr int NFRAG = TM / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = a.K;
     const int KS = K | 1;  // odd row pitch: conflict-free column reads of the rulebook tile
     const int cg = a.cg;
     const int n_groups = a.n_steps / cg;
-    uint4* s_w = reinterpret_cast<uint4*>(smem);                                   // cg * NT * 64 uint4
-    int* s_nbr = reinterpret_cast<int*>(smem + (size_t)cg * NT * 1024);             // TM * KS
+    u32x4* s_w = reinterpret_cast<u32x4*>(smem);                                    // 2 slots x cg * NT * 64 vectors
+    int* s_nbr = reinterpret_cast<int*>(smem + (size_t)2 * cg * NT * 1024);         // TM * KS
     int* s_valid = s_nbr + TM * KS;                                                 // K fragment masks
     int* s_grp = s_valid + ((K + 3) & ~3);                                          // n_groups + 1 (last = count)
-    int* s_masks = s_grp + n_groups + 1;                                            // n_groups fragment masks
+    int* s_masks = s_grp + n_groups + 1;                                            // n_groups + 1 fragment masks
+    int* s_gko = s_masks + n_groups + 1;                                            // n_groups + 1: offset | sub-group << 16
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform for the compiler
@@ -190,18 +206,21 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     __syncthreads();
     // ordered list of the groups that touch at least one populated offset, with their fragment masks (wave 0)
     const int vpo = a.vpo;
+    const bool wide = (vpo & 3) == 0;
+    const int gpo = wide ? (vpo >> 2) / cg : 1;          // groups per offset (wide layers)
     if (wave == 0) {
         int base = 0;
         for (int g0 = 0; g0 < n_groups; g0 += 64) {
             const int gi = g0 + lane;
-            int fm = 0;
+            int fm = 0, ko = 0;
             if (gi < n_groups) {
-                if ((vpo & 3) == 0) {
-                    fm = s_valid[gi / ((vpo >> 2) / cg)];
+                if (wide) {
+                    ko = gi / gpo;
+                    fm = s_valid[ko];
                 } else {
                     for (int q = 0; q < 4; ++q) {
-                        const int ko = (gi * 4 + q) / vpo;
-                        if (ko < K) fm |= s_valid[ko];
+                        const int kq = (gi * 4 + q) / vpo;
+                        if (kq < K) fm |= s_valid[kq];
                     }
                 }
             }
@@ -211,6 +230,7 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
                 const int pos = base + __popcll(m & ((1ULL << lane) - 1ULL));
                 s_grp[pos] = gi;
                 s_masks[pos] = fm | ((a.dbg & 1) ? 0xffff : 0);
+                s_gko[pos] = ko | ((gi - ko * gpo) << 16);
             }
             base += __popcll(m);
         }
@@ -232,117 +252,139 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
         for (int t = 0; t < NT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int g = lane >> 4, rl = lane & 15;
-    constexpr int WPIECES = NT * 128;                                   // 8-byte pieces of one step's weight tile
-    constexpr int WREGS = (WPIECES + CONV_TPB - 1) / CONV_TPB;          // = NT/2 for even NT (no predication)
-    uint2* s_w2 = reinterpret_cast<uint2*>(s_w);
 
     // Both operands come in through buffer resources: a gather is ONE instruction with a 32-bit per-lane byte offset,
     // and a fragment without a neighbour simply uses an out-of-range offset -- the hardware bounds check returns
     // zeros, so the inner loop has no exec-mask branches and no 64-bit address arithmetic.  (Slabs must stay < 2 GiB.)
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, 0x80000000u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, 0x80000000u, 0x00020000);
+    const unsigned long long in_addr = (unsigned long long)a.in, w_addr = (unsigned long long)a.w;
+    const i32x4 rs_in = {(int)(unsigned)in_addr, (int)(unsigned)(in_addr >> 32), (int)0x80000000u, 0x00020000};
+    const i32x4 rs_w = {(int)(unsigned)w_addr, (int)(unsigned)(w_addr >> 32), (int)0x80000000u, 0x00020000};
     constexpr unsigned OOB = 0x80000000u;  // >= num_records: the bounds check turns the load into zeros
     const unsigned ld_bytes = (unsigned)a.ld_in * (unsigned)sizeof(T);
     const int vshift = (vpo == 2) ? 1 : 0;
-    const int spo = (vpo & 3) == 0 ? (vpo >> 2) : 1;   // steps per offset (wide layers)
-    const int gpo = spo / cg;                            // groups per offset (wide layers)
-    const unsigned w_tile_bytes = (unsigned)a.ntiles_total * 1024u;   // one step, all channel tiles
-    const unsigned w_voff = (unsigned)tid * 8u;
+    const unsigned w_step_bytes = (unsigned)a.ntiles_total * 1024u;   // one step, all channel tiles
+    const unsigned w_lane = (unsigned)lane * 16u;
+    const unsigned slot_bytes = (unsigned)cg * NT * 1024u;
+    const unsigned lds_w = PBN_LDS_ADDR(s_w);
 
-    // per-group gather offsets: every chunk of a group reads the same neighbour row at +64 B per chunk
-#define PBN_GROUP_ROWS(GI, VOFF)                                                                                      \
+    // gather byte offsets of group-list entry POS (all out of range when MORE is false): every chunk of a group reads
+    // the same neighbour row, +64 B per chunk
+#define PBN_GROUP_ROWS(POS, GI, MORE, VOFF, CG)                                                                       \
     {                                                                                                                 \
         int ko_, cv_;                                                                                                 \
-        if ((vpo & 3) == 0) { ko_ = (GI) / gpo; cv_ = ((GI) - ko_ * gpo) * cg * 4 + g; }                              \
-        else { const int v_ = (GI) * 4 + g; ko_ = v_ >> vshift; cv_ = v_ & (vpo - 1); }                               \
+        if (wide) {                                                                                                   \
+            const int pk_ = __builtin_amdgcn_readfirstlane(s_gko[POS]);                                               \
+            ko_ = pk_ & 0xffff; cv_ = (pk_ >> 16) * (CG) * 4 + g;                                                     \
+        } else { const int v_ = (GI) * 4 + g; ko_ = v_ >> vshift; cv_ = v_ & (vpo - 1); }                             \
         _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                              \
             const int r_ = wave * RW + f * 16 + rl;                                                                   \
-            const int src_ = (ko_ < K) ? s_nbr[r_ * KS + ko_] : -1;                                                   \
+            const int src_ = ((MORE) && ko_ < K) ? s_nbr[r_ * KS + ko_] : -1;                                         \
             VOFF[f] = (src_ >= 0 && !(a.dbg & 4)) ? (unsigned)src_ * ld_bytes + (unsigned)cv_ * 16u : OOB;            \
         }                                                                                                             \
     }
-#define PBN_LOAD_X(VOFF, C, X)                                                                                        \
+    // refill chunk C's operand registers in place ("+v": the load lands in the register the MFMAs just read)
+#define PBN_LOAD_X(VOFF, C)                                                                                           \
     {                                                                                                                 \
         _Pragma("unroll") for (int f = 0; f < NF; ++f)                                                                \
-            X[f] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, VOFF[f], (C) * 64, 0));     \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen"                                                   \
+                         : "+v"(x[C][f]) : "v"(VOFF[f]), "s"(rs_in), "s"((C) * 64));                                  \
     }
-#define PBN_LOAD_WGROUP(GI)                                                                                           \
+    // wait until at most N vector-memory loads are outstanding; names chunk C's registers so that their readers
+    // are ordered behind the wait
+#define PBN_WAIT_X(C, N)                                                                                              \
     {                                                                                                                 \
-        const unsigned gbase_ = ((unsigned)(GI) * cg * a.ntiles_total + tile0) * 1024u;                               \
-        _Pragma("unroll") for (int c = 0; c < CGMAX; ++c) {                                                           \
-            if (c < cg) {                                                                                             \
-                _Pragma("unroll") for (int i = 0; i < WREGS; ++i) {                                                   \
-                    const unsigned vo_ = (WPIECES % CONV_TPB == 0 || tid + i * CONV_TPB < WPIECES)                    \
-                                             ? w_voff + i * (CONV_TPB * 8u) : OOB;                                    \
-                    wr[c][i] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(                        \
-                                                           rs_w, (a.dbg & 8) ? OOB : vo_, gbase_ + c * w_tile_bytes, 0)); \
-                }                                                                                                     \
-            }                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x[C][0]) : "n"(N));                                                 \
+        _Pragma("unroll") for (int f = 1; f < NF; ++f) asm volatile("" : "+v"(x[C][f]));                              \
+    }
+    // weight tile of group GI -> ring slot at LDS byte address SLOT: piece p = wave + 4 i is step p / NT, channel tile
+    // p % NT; every wave issues the same number of pieces (the tail is clamped onto the last piece: a benign duplicate
+    // copy).  MORE false (past the last group): the same instructions with an out-of-range offset: no memory traffic.
+#define PBN_DMA_W(GI, MORE, SLOT, CG)                                                                                 \
+    {                                                                                                                 \
+        const unsigned gbase_ = ((unsigned)(GI) * (CG) * a.ntiles_total + tile0) * 1024u;                             \
+        const unsigned wv_ = ((MORE) && !(a.dbg & 8)) ? w_lane : OOB;                                                 \
+        _Pragma("unroll") for (int i = 0; i < ((CG) * NT + 3) / 4; ++i) {                                             \
+            const int p_ = min(wave + 4 * i, (CG) * NT - 1);                                                          \
+            const int c_ = p_ / NT, t_ = p_ - c_ * NT;                                                                \
+            unsigned keep_;                                                                                           \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"                                        \
+                         "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"                               \
+                         : "=&s"(keep_)                                                                               \
+                         : "s"((SLOT) + (unsigned)p_ * 1024u), "v"(wv_), "s"(rs_w),                                   \
+                           "s"(gbase_ + c_ * w_step_bytes + t_ * 1024u)                                               \
+                         : "memory");                                                                                 \
         }                                                                                                             \
     }
-#define PBN_STORE_WGROUP()                                                                                            \
+#define PBN_LOAD_WF(DST, CUR, C)                                                                                      \
+    { _Pragma("unroll") for (int t = 0; t < NT; ++t) DST[t] = CUR[((C) * NT + t) * 64 + lane]; }
+    // one group.  Loads in flight at the top, oldest first: DMA(this group), x[0..CG-1](this group).
+    //   barrier  : vmcnt(CG*NF) = the DMA has landed (every wave's pieces, hence the barrier); the other slot is free
+    //   chunk c  : loads behind x[c](this group) = x[c+1..](this), DMA(next), x[..c-1](next) = (CG-1)*NF + PW
+#define PBN_GROUP(POS, CG)                                                                                            \
     {                                                                                                                 \
-        _Pragma("unroll") for (int c = 0; c < CGMAX; ++c) {                                                           \
-            if (c < cg) {                                                                                             \
-                _Pragma("unroll") for (int i = 0; i < WREGS; ++i) {                                                   \
-                    const int q_ = tid + i * CONV_TPB;                                                                \
-                    if (WPIECES % CONV_TPB == 0 || q_ < WPIECES) s_w2[c * WPIECES + q_] = wr[c][i];                   \
+        constexpr int PW_ = ((CG) * NT + 3) / 4;                                                                      \
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"((CG) * NF) : "memory");                               \
+        const bool active_ = (fcur & my_bits) && !(a.dbg & 2);                                                        \
+        const bool more_ = (POS) + 1 < ng;                                                                            \
+        const u32x4* cur_ = s_w + par * ((CG) * NT * 64);                                                             \
+        par ^= 1;                                                                                                     \
+        unsigned vnext_[NF];                                                                                          \
+        {                                                                                                             \
+            const int gnext_ = __builtin_amdgcn_readfirstlane(s_grp[(POS) + 1]);                                      \
+            const unsigned fnext_ = (unsigned)__builtin_amdgcn_readfirstlane(s_masks[(POS) + 1]);                     \
+            fcur = more_ ? fnext_ : 0u;                                                                               \
+            PBN_DMA_W(gnext_, more_, lds_w + par * slot_bytes, CG);                                                   \
+            PBN_GROUP_ROWS((POS) + 1, gnext_, more_, vnext_, CG);                                                     \
+        }                                                                                                             \
+        /* the asm statements that define x[][] stay on the straight-line path: inside a branch the compiler would */ \
+        /* merge them through register copies, i.e. read registers whose loads are still in flight                 */ \
+        u32x4 wf_[2][NT];                                                                                             \
+        if (active_) PBN_LOAD_WF(wf_[0], cur_, 0);                                                                    \
+        _Pragma("unroll") for (int c = 0; c < (CG); ++c) {                                                            \
+            PBN_WAIT_X(c, ((CG) - 1) * NF + PW_);                                                                     \
+            if (active_) {                                                                                            \
+                if (c + 1 < (CG)) PBN_LOAD_WF(wf_[(c + 1) & 1], cur_, c + 1);                                         \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
+                    _Pragma("unroll") for (int f = 0; f < NF; ++f) mfma_step<T>(wf_[c & 1][t], x[c][f], acc[f][t]);   \
                 }                                                                                                     \
             }                                                                                                         \
+            PBN_LOAD_X(vnext_, c);                                                                                    \
         }                                                                                                             \
+    }
+#define PBN_MAINLOOP(CG)                                                                                              \
+    {                                                                                                                 \
+        u32x4 x[CG][NF];                                                                                              \
+        _Pragma("unroll") for (int c = 0; c < (CG); ++c)                                                              \
+            _Pragma("unroll") for (int f = 0; f < NF; ++f) x[c][f] = u32x4{0u, 0u, 0u, 0u};                           \
+        unsigned fcur = (unsigned)__builtin_amdgcn_readfirstlane(s_masks[g_lo]);                                      \
+        unsigned par = 0;                                                                                             \
+        {                                                                                                             \
+            const int g0_ = __builtin_amdgcn_readfirstlane(s_grp[g_lo]);                                              \
+            unsigned v0_[NF];                                                                                         \
+            PBN_DMA_W(g0_, true, lds_w, CG);                                                                          \
+            PBN_GROUP_ROWS(g_lo, g0_, true, v0_, CG);                                                                 \
+            _Pragma("unroll") for (int c = 0; c < (CG); ++c) { PBN_LOAD_X(v0_, c); }                                  \
+        }                                                                                                             \
+        for (int pos = g_lo; pos < ng; ++pos) PBN_GROUP(pos, CG);                                                     \
+        /* drain: the loads issued for the (non-existent) group past the end still target these registers */         \
+        _Pragma("unroll") for (int c = 0; c < (CG); ++c) { PBN_WAIT_X(c, 0); }                                        \
     }
 
     if (ng > g_lo && !(a.dbg & 16)) {
-        // Software pipeline at GROUP granularity: while the matrix cores work through group i (cg chunks x NT x NF MFMAs),
-        // the weight tile AND every gather of group i+1 are already in flight; they are consumed after the next barrier.
-        uint4 xc[CGMAX][NF], xn[CGMAX][NF];
-        unsigned vnext[NF];
-        uint2 wr[CGMAX][WREGS];
-        int gcur = __builtin_amdgcn_readfirstlane(s_grp[g_lo]);
-        unsigned fcur = (unsigned)__builtin_amdgcn_readfirstlane(s_masks[g_lo]);
-        PBN_LOAD_WGROUP(gcur);
-        PBN_GROUP_ROWS(gcur, vnext);
-#pragma unroll
-        for (int c = 0; c < CGMAX; ++c)
-            if (c < cg) { PBN_LOAD_X(vnext, c, xn[c]); }
-        for (int gi = g_lo; gi < ng; ++gi) {
-            // swap the weight tile: everybody is done with the previous group's tile, then publish this group's
-            __syncthreads();
-            PBN_STORE_WGROUP();
-#pragma unroll
-            for (int c = 0; c < CGMAX; ++c)
-#pragma unroll
-                for (int f = 0; f < NF; ++f) xc[c][f] = xn[c][f];
-            __syncthreads();
-            const bool active = (fcur & my_bits) && !(a.dbg & 2);  // wave-uniform: any of this wave's fragments populated
-            if (gi + 1 < ng) {
-                const int gnext = __builtin_amdgcn_readfirstlane(s_grp[gi + 1]);
-                fcur = (unsigned)__builtin_amdgcn_readfirstlane(s_masks[gi + 1]);
-                PBN_LOAD_WGROUP(gnext);
-                PBN_GROUP_ROWS(gnext, vnext);
-#pragma unroll
-                for (int c = 0; c < CGMAX; ++c)
-                    if (c < cg) { PBN_LOAD_X(vnext, c, xn[c]); }
-            }
-            if (active) {
-#pragma unroll
-                for (int c = 0; c < CGMAX; ++c) {
-                    if (c < cg) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            const uint4 wf = s_w[(c * NT + t) * 64 + lane];
-#pragma unroll
-                            for (int f = 0; f < NF; ++f) mfma_step<T>(wf, xc[c][f], acc[f][t]);
-                        }
-                    }
-                }
-            }
+        switch (cg) {
+            case 4: PBN_MAINLOOP(4); break;
+            case 3: PBN_MAINLOOP(3); break;
+            case 2: PBN_MAINLOOP(2); break;
+            default: PBN_MAINLOOP(1); break;
         }
     }
+#undef PBN_MAINLOOP
+#undef PBN_GROUP
+#undef PBN_LOAD_WF
+#undef PBN_DMA_W
+#undef PBN_WAIT_X
 #undef PBN_GROUP_ROWS
 #undef PBN_LOAD_X
-#undef PBN_LOAD_WGROUP
-#undef PBN_STORE_WGROUP
 
     if (a.ksplit > 1) {  // raw fp32 partial sums, tile-position rows; the epilogue runs in k_spconv_reduce
         const int ldp = a.ntiles_total * 16;
@@ -423,9 +465,9 @@ __global__ __launch_bounds__(256) void k_spconv_reduce(const ConvArgs a) {
     store4<T>(reinterpret_cast<T*>(a.out) + (size_t)orow * a.ld_out + c0, v);
 }
 
-template <typename T, int RW, int NT>
+template <typename T, int NF, int NT>
 int launch_one(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes, hipStream_t stream) {
-    constexpr int TM = 4 * RW;
+    constexpr int TM = 64 * NF;
     const int KS = a.K | 1;
     // steps per barrier group: the largest divisor <= 4 of the steps per offset (1 when offsets are narrower than a step)
     a.cg = 1;
@@ -435,9 +477,9 @@ int launch_one(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes
             if (spo % c == 0) { a.cg = c; break; }
     }
     const int n_groups = a.n_steps / a.cg;
-    const size_t lds = (size_t)a.cg * NT * 1024 + sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 2 * (size_t)n_groups + 1);
+    const size_t lds = (size_t)2 * a.cg * NT * 1024 + sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 3 * ((size_t)n_groups + 1));
     if (lds > 160 * 1024) return PBN_ERR_UNSUPPORTED;
-    auto kern = k_spconv<T, RW, NT>;
+    auto kern = k_spconv<T, NF, NT>;
     if (lds > 64 * 1024)
         PBN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tiles = cdiv(a.n_out, TM);
@@ -465,21 +507,21 @@ int launch_one(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes
     return PBN_OK;
 }
 
-template <typename T, int RW>
+template <typename T, int NF>
 int launch_nt(const ConvArgs& a, float* ws, size_t wsb, hipStream_t stream) {
     const int ntt = a.ntiles_total;
-    if (ntt % 8 == 0) return launch_one<T, RW, 8>(a, ntt / 8, ws, wsb, stream);
-    if (ntt % 6 == 0) return launch_one<T, RW, 6>(a, ntt / 6, ws, wsb, stream);
-    if (ntt % 4 == 0) return launch_one<T, RW, 4>(a, ntt / 4, ws, wsb, stream);
-    if (ntt % 2 == 0) return launch_one<T, RW, 2>(a, ntt / 2, ws, wsb, stream);
-    return launch_one<T, RW, 1>(a, ntt, ws, wsb, stream);
+    if (ntt % 8 == 0) return launch_one<T, NF, 8>(a, ntt / 8, ws, wsb, stream);
+    if (ntt % 6 == 0) return launch_one<T, NF, 6>(a, ntt / 6, ws, wsb, stream);
+    if (ntt % 4 == 0) return launch_one<T, NF, 4>(a, ntt / 4, ws, wsb, stream);
+    if (ntt % 2 == 0) return launch_one<T, NF, 2>(a, ntt / 2, ws, wsb, stream);
+    return launch_one<T, NF, 1>(a, ntt, ws, wsb, stream);
 }
 
 template <typename T>
 int launch_t(const ConvArgs& a, int rows_per_wave, float* ws, size_t wsb, hipStream_t stream) {
-    if (rows_per_wave == 64) return launch_nt<T, 64>(a, ws, wsb, stream);
-    if (rows_per_wave == 32) return launch_nt<T, 32>(a, ws, wsb, stream);
-    return launch_nt<T, 16>(a, ws, wsb, stream);
+    if (rows_per_wave == 64) return launch_nt<T, 4>(a, ws, wsb, stream);
+    if (rows_per_wave == 32) return launch_nt<T, 2>(a, ws, wsb, stream);
+    return launch_nt<T, 1>(a, ws, wsb, stream);
 }
 
 // ---- row gather: out[i, :] = in[idx[i], :]  (voxel -> point, PBNet.py:130-134) ----------------------------------
