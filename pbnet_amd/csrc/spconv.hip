@@ -146,7 +146,7 @@ constexpr int CGMAX = 4;  // channel chunks (steps) per group
 // complete in issue order, so "the DMA of this group has landed" and "chunk c has landed" are fixed counts of the
 // loads issued after them -- the barrier never waits for the gathers behind the DMA, an MFMA never waits for a DMA.
 // (hipcc's own wait-count insertion is conservative across the loop's branches and drains the queue.)
-template <typename T, int NF, int NT>
+template <typename T, int NF, int NT, int RING>
 __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     static_assert(Tr<T>::ELEMS * sizeof(T) == 16, "one gather vector is 16 bytes");
     constexpr int RW = NF * 16;
@@ -157,12 +157,13 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     const int KS = K | 1;  // odd row pitch: conflict-free column reads of the rulebook tile
     const int cg = a.cg;
     const int n_groups = a.n_steps / cg;
-    u32x4* s_w = reinterpret_cast<u32x4*>(smem);                                    // 2 slots x cg * NT * 64 vectors
-    int* s_nbr = reinterpret_cast<int*>(smem + (size_t)2 * cg * NT * 1024);         // TM * KS
+    constexpr int DEPTH = RING - 1;                                                 // weight tiles in flight ahead
+    u32x4* s_w = reinterpret_cast<u32x4*>(smem);                                    // RING slots x cg * NT * 64 vectors
+    int* s_nbr = reinterpret_cast<int*>(smem + (size_t)RING * cg * NT * 1024);      // TM * KS
     int* s_valid = s_nbr + TM * KS;                                                 // K fragment masks
-    int* s_grp = s_valid + ((K + 3) & ~3);                                          // n_groups + 1 (last = count)
-    int* s_masks = s_grp + n_groups + 1;                                            // n_groups + 1 fragment masks
-    int* s_gko = s_masks + n_groups + 1;                                            // n_groups + 1: offset | sub-group << 16
+    int* s_grp = s_valid + ((K + 3) & ~3);                                          // n_groups + 4 (entry n_groups = count)
+    int* s_masks = s_grp + n_groups + 4;                                            // n_groups + 4 fragment masks
+    int* s_gko = s_masks + n_groups + 4;                                            // n_groups + 4: offset | sub-group << 16
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform for the compiler
@@ -310,30 +311,34 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"                                        \
                          "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"                               \
                          : "=&s"(keep_)                                                                               \
-                         : "s"((SLOT) + (unsigned)p_ * 1024u), "v"(wv_), "s"(rs_w),                                   \
-                           "s"(gbase_ + c_ * w_step_bytes + t_ * 1024u)                                               \
+                         : "s"(__builtin_amdgcn_readfirstlane((SLOT) + (unsigned)p_ * 1024u)), "v"(wv_), "s"(rs_w),   \
+                           "s"(__builtin_amdgcn_readfirstlane(gbase_ + c_ * w_step_bytes + t_ * 1024u))               \
                          : "memory");                                                                                 \
         }                                                                                                             \
     }
 #define PBN_LOAD_WF(DST, CUR, C)                                                                                      \
     { _Pragma("unroll") for (int t = 0; t < NT; ++t) DST[t] = CUR[((C) * NT + t) * 64 + lane]; }
-    // one group.  Loads in flight at the top, oldest first: DMA(this group), x[0..CG-1](this group).
-    //   barrier  : vmcnt(CG*NF) = the DMA has landed (every wave's pieces, hence the barrier); the other slot is free
-    //   chunk c  : loads behind x[c](this group) = x[c+1..](this), DMA(next), x[..c-1](next) = (CG-1)*NF + PW
+    // one group.  Issue order per group body j: DMA(j + DEPTH), then x[0..CG-1](j + 1), hence at the top of group g:
+    //   barrier  : loads issued behind DMA(g) = CG*NF + (DEPTH-1) * (PW + CG*NF): wait for exactly that count = every
+    //              wave's pieces of this group's weight tile have landed (hence the barrier); the slot of group g-1 is free
+    //   chunk c  : loads behind x[c](g) = x[c+1..](g), DMA(g + DEPTH), x[..c-1](g + 1) = (CG-1)*NF + PW
 #define PBN_GROUP(POS, CG)                                                                                            \
     {                                                                                                                 \
         constexpr int PW_ = ((CG) * NT + 3) / 4;                                                                      \
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"((CG) * NF) : "memory");                               \
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier"                                                               \
+                     : : "n"((CG) * NF + (DEPTH - 1) * (PW_ + (CG) * NF)) : "memory");                                \
         const bool active_ = (fcur & my_bits) && !(a.dbg & 2);                                                        \
         const bool more_ = (POS) + 1 < ng;                                                                            \
-        const u32x4* cur_ = s_w + par * ((CG) * NT * 64);                                                             \
-        par ^= 1;                                                                                                     \
+        const u32x4* cur_ = s_w + slot * ((CG) * NT * 64);                                                            \
+        const unsigned free_ = slot == 0 ? RING - 1 : slot - 1;   /* slot of group POS-1 = slot of group POS+DEPTH */  \
+        slot = slot == RING - 1 ? 0 : slot + 1;                                                                       \
         unsigned vnext_[NF];                                                                                          \
         {                                                                                                             \
+            const int gdma_ = __builtin_amdgcn_readfirstlane(s_grp[(POS) + DEPTH]);                                   \
+            PBN_DMA_W(gdma_, (POS) + DEPTH < ng, lds_w + free_ * slot_bytes, CG);                                     \
             const int gnext_ = __builtin_amdgcn_readfirstlane(s_grp[(POS) + 1]);                                      \
             const unsigned fnext_ = (unsigned)__builtin_amdgcn_readfirstlane(s_masks[(POS) + 1]);                     \
             fcur = more_ ? fnext_ : 0u;                                                                               \
-            PBN_DMA_W(gnext_, more_, lds_w + par * slot_bytes, CG);                                                   \
             PBN_GROUP_ROWS((POS) + 1, gnext_, more_, vnext_, CG);                                                     \
         }                                                                                                             \
         /* the asm statements that define x[][] stay on the straight-line path: inside a branch the compiler would */ \
@@ -351,18 +356,21 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
             PBN_LOAD_X(vnext_, c);                                                                                    \
         }                                                                                                             \
     }
+    // prologue: the same issue pattern as DEPTH loop bodies (the gathers behind all but the last DMA are dummies with
+    // out-of-range offsets) so that the loop's wait counts hold from the first group on
 #define PBN_MAINLOOP(CG)                                                                                              \
     {                                                                                                                 \
         u32x4 x[CG][NF];                                                                                              \
         _Pragma("unroll") for (int c = 0; c < (CG); ++c)                                                              \
             _Pragma("unroll") for (int f = 0; f < NF; ++f) x[c][f] = u32x4{0u, 0u, 0u, 0u};                           \
         unsigned fcur = (unsigned)__builtin_amdgcn_readfirstlane(s_masks[g_lo]);                                      \
-        unsigned par = 0;                                                                                             \
-        {                                                                                                             \
-            const int g0_ = __builtin_amdgcn_readfirstlane(s_grp[g_lo]);                                              \
+        unsigned slot = 0;                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < DEPTH; ++j) {                                                           \
+            const int gj_ = __builtin_amdgcn_readfirstlane(s_grp[g_lo + j]);                                          \
             unsigned v0_[NF];                                                                                         \
-            PBN_DMA_W(g0_, true, lds_w, CG);                                                                          \
-            PBN_GROUP_ROWS(g_lo, g0_, true, v0_, CG);                                                                 \
+            PBN_DMA_W(gj_, g_lo + j < ng, lds_w + (unsigned)j * slot_bytes, CG);                                      \
+            const int g0_ = __builtin_amdgcn_readfirstlane(s_grp[g_lo]);                                              \
+            PBN_GROUP_ROWS(g_lo, g0_, j == DEPTH - 1, v0_, CG);                                                       \
             _Pragma("unroll") for (int c = 0; c < (CG); ++c) { PBN_LOAD_X(v0_, c); }                                  \
         }                                                                                                             \
         for (int pos = g_lo; pos < ng; ++pos) PBN_GROUP(pos, CG);                                                     \
@@ -465,8 +473,8 @@ __global__ __launch_bounds__(256) void k_spconv_reduce(const ConvArgs a) {
     store4<T>(reinterpret_cast<T*>(a.out) + (size_t)orow * a.ld_out + c0, v);
 }
 
-template <typename T, int NF, int NT>
-int launch_one(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes, hipStream_t stream) {
+template <typename T, int NF, int NT, int RING>
+int launch_ring(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes, hipStream_t stream) {
     constexpr int TM = 64 * NF;
     const int KS = a.K | 1;
     // steps per barrier group: the largest divisor <= 4 of the steps per offset (1 when offsets are narrower than a step)
@@ -477,9 +485,9 @@ int launch_one(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes
             if (spo % c == 0) { a.cg = c; break; }
     }
     const int n_groups = a.n_steps / a.cg;
-    const size_t lds = (size_t)2 * a.cg * NT * 1024 + sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 3 * ((size_t)n_groups + 1));
+    const size_t lds = (size_t)RING * a.cg * NT * 1024 + sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 3 * ((size_t)n_groups + 4));
     if (lds > 160 * 1024) return PBN_ERR_UNSUPPORTED;
-    auto kern = k_spconv<T, NF, NT>;
+    auto kern = k_spconv<T, NF, NT, RING>;
     if (lds > 64 * 1024)
         PBN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tiles = cdiv(a.n_out, TM);
@@ -489,8 +497,9 @@ int launch_one(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes
     a.partial = nullptr;
     a.n_out_pad = tiles * TM;
     const long long wgs = (long long)tiles * ngroups;
-    if (workspace && wgs < 384 && n_groups >= 8) {
-        long long want = (768 + wgs - 1) / wgs;
+    static const int split_target = getenv("PBN_CONV_SPLIT") ? atoi(getenv("PBN_CONV_SPLIT")) : 384;
+    if (workspace && wgs < split_target / 2 && n_groups >= 8) {
+        long long want = (split_target + wgs - 1) / wgs;
         const long long by_steps = n_groups / 2;
         const long long by_ws = (long long)(workspace_bytes / ((size_t)a.n_out_pad * a.ntiles_total * 16 * sizeof(float)));
         if (want > by_steps) want = by_steps;
@@ -505,6 +514,13 @@ int launch_one(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes
     }
     PBN_LAUNCH_CHECK();
     return PBN_OK;
+}
+
+template <typename T, int NF, int NT>
+int launch_one(const ConvArgs& a, int ngroups, float* ws, size_t wsb, hipStream_t stream) {
+    // RING = 3 (two weight tiles in flight) was measured slower on every level of the bench scene: the third slot costs
+    // a workgroup per CU and the chains are not DMA-latency bound.  The template parameter stays for re-tuning.
+    return launch_ring<T, NF, NT, 2>(a, ngroups, ws, wsb, stream);
 }
 
 template <typename T, int NF>
