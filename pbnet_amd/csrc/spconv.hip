@@ -497,7 +497,7 @@ int launch_ring(ConvArgs a, int ngroups, float* workspace, size_t workspace_byte
     a.partial = nullptr;
     a.n_out_pad = tiles * TM;
     const long long wgs = (long long)tiles * ngroups;
-    static const int split_target = getenv("PBN_CONV_SPLIT") ? atoi(getenv("PBN_CONV_SPLIT")) : 384;
+    static const int split_target = getenv("PBN_CONV_SPLIT") ? atoi(getenv("PBN_CONV_SPLIT")) : 256;
     if (workspace && wgs < split_target / 2 && n_groups >= 8) {
         long long want = (split_target + wgs - 1) / wgs;
         const long long by_steps = n_groups / 2;
