@@ -167,9 +167,12 @@ int pbn_gather_rows(const void* in, int ld_in_bytes, const int64_t* idx, int n, 
 /* Per-batch global max and/or average pooling of a slab whose rows are grouped by batch index
  * (MinkowskiGlobalMaxPooling / MinkowskiGlobalAvgPooling of the score branch, network/PBNet.py:67-68,274-276).
  * seg_start int32[n_seg+1] row offsets; out_max / out_avg f32 [n_seg, channels] (either may be NULL).
- * An empty segment yields -inf / NaN exactly like the reductions it replaces.  Deterministic. */
+ * An empty segment yields -inf / NaN exactly like the reductions it replaces.  Deterministic.
+ * workspace (optional, pbn_segment_pool_workspace_bytes): lets long segments be reduced by many workgroups in two
+ * fixed-order passes; without it every (segment, 32-channel chunk) is one workgroup. */
+size_t pbn_segment_pool_workspace_bytes(int n_seg, int channels);
 int pbn_segment_pool(const void* feats, int ld, int channels, int dtype, const int32_t* seg_start, int n_seg,
-                     float* out_max, float* out_avg, pbn_stream_t stream);
+                     float* out_max, float* out_avg, void* workspace, size_t workspace_bytes, pbn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * One-call sub-pipelines (csrc/executor.hip): they only sequence the entry points above.

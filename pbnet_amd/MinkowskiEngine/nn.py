@@ -73,8 +73,11 @@ def segment_pool(feats, batch_sorted, n_batch, want_max=True, want_avg=True):
     c = feats.shape[1]
     mx = torch.empty(n_batch, c, dtype=torch.float32, device=feats.device) if want_max else None
     av = torch.empty(n_batch, c, dtype=torch.float32, device=feats.device) if want_avg else None
-    rc = N.lib().pbn_segment_pool(N.c_vp(feats.data_ptr()), feats.stride(0), c, _DT[feats.dtype], N.ptr(seg_start),
-                                  int(n_batch), N.ptr(mx), N.ptr(av), N.current_stream())
+    lib = N.lib()
+    ws_bytes = int(lib.pbn_segment_pool_workspace_bytes(int(n_batch), c))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=feats.device)
+    rc = lib.pbn_segment_pool(N.c_vp(feats.data_ptr()), feats.stride(0), c, _DT[feats.dtype], N.ptr(seg_start),
+                              int(n_batch), N.ptr(mx), N.ptr(av), N.c_vp(ws.data_ptr()), ws_bytes, N.current_stream())
     N.check(rc, "pbn_segment_pool")
     return mx, av
 

@@ -211,6 +211,30 @@ def test_linear_heads_and_pooling():
     assert ((mx + avg).F.cpu() - (R.global_pool(want, b, 3, "avg") + R.global_pool(want, b, 3, "max"))).abs().max() <= 1e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_segment_pool_long_and_ragged_segments(dtype):
+    """Score-branch pooling (PBNet.py:274-276) at proposal-sized segments: one long, several short, one empty; the
+    two-pass kernel must agree with a per-segment fp32 reduction and be run-to-run identical."""
+    from pbnet_amd.MinkowskiEngine.nn import segment_pool
+    torch.manual_seed(9)
+    lens = [20011, 3, 0, 777, 1, 4096, 130]
+    feats = torch.randn(sum(lens), 32).to(dtype)
+    batch = torch.repeat_interleave(torch.arange(len(lens)), torch.tensor(lens)).to(torch.int32)
+    mx, av = segment_pool(feats.to(DEV), batch.to(DEV), len(lens))
+    mx2, av2 = segment_pool(feats.to(DEV), batch.to(DEV), len(lens))
+    assert torch.equal(mx, mx2) and torch.equal(av.nan_to_num(), av2.nan_to_num())
+    f32 = feats.float()
+    o = 0
+    for i, n in enumerate(lens):
+        seg = f32[o:o + n]
+        o += n
+        if n == 0:
+            assert torch.isinf(mx[i]).all() and torch.isnan(av[i]).all()
+            continue
+        assert torch.equal(mx[i].cpu(), seg.max(0)[0])
+        assert (av[i].cpu() - seg.double().mean(0).float()).abs().max().item() <= 1e-5
+
+
 def test_full_size_scene_linearity_and_determinism():
     """BASELINE configs[1] size (145k voxels): convolution is linear in its input, independent of row-tile shape,
     and bit-reproducible run to run (fixed summation order)."""
