@@ -73,39 +73,115 @@ __global__ __launch_bounds__(TPB) void k_insert_rows(const int* __restrict__ coo
     slot_of_row[i] = table_insert_min(keys, vals, mask, pack4(c.x, c.y, c.z, c.w), i);
 }
 
-__global__ __launch_bounds__(TPB) void k_first_flags(const int* __restrict__ slot_of_row, const int* __restrict__ vals,
-                                                    const int* n_dev, int n_max, int* __restrict__ flags) {
-    const int i = blockIdx.x * TPB + threadIdx.x;
-    if (i >= n_max) return;
-    flags[i] = (i < real_n(n_dev, n_max) && vals[slot_of_row[i]] == i) ? 1 : 0;
+// "row i is the first occurrence of its key": the slot's value is the smallest inserting row
+__device__ __forceinline__ int first_flag(const int* __restrict__ slot_of_row, const int* __restrict__ vals, int i, int n) {
+    return (i < n && vals[slot_of_row[i]] == i) ? 1 : 0;
 }
 
-// unique_index[new] = first row; inverse[i] = new id of i's survivor
-__global__ __launch_bounds__(TPB) void k_unique_write(const int* __restrict__ slot_of_row, const int* __restrict__ vals,
-                                                     const int* __restrict__ flags, const int* __restrict__ newid,
+__device__ __forceinline__ int wave_incl_scan_i(int v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Survivor numbering = exclusive scan of the first-occurrence flags, in two launches instead of flags + 3-launch scan:
+//   k_flag_block_sums : per 2048-row block, the number of first rows;
+//   k_flag_number     : every block sums the block totals in front of it (a few hundred ints, L2-resident), scans its
+//                       own flags, writes newid[i] and first_row[i] (the slot's value BEFORE any renumbering, so that
+//                       the write kernels can renumber the table in place without racing their own readers);
+//                       the last block publishes the survivor count (or -1 on a range error).
+__global__ __launch_bounds__(SCAN_THREADS) void k_flag_block_sums(const int* __restrict__ slot_of_row,
+                                                                  const int* __restrict__ vals, const int* n_dev,
+                                                                  int n_max, int* __restrict__ sums) {
+    __shared__ int wtot[SCAN_THREADS / 64];
+    const int n = real_n(n_dev, n_max);
+    const int base = blockIdx.x * SCAN_TILE;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) s += first_flag(slot_of_row, vals, base + k * SCAN_THREADS + threadIdx.x, n);
+    s = wave_reduce_add(s);
+    if (lane_id() == 0) wtot[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) t += wtot[w];
+        sums[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_flag_number(const int* __restrict__ slot_of_row,
+                                                              const int* __restrict__ vals, const int* n_dev, int n_max,
+                                                              const int* __restrict__ sums, int* __restrict__ newid,
+                                                              int* __restrict__ first_row, int* __restrict__ n_out,
+                                                              const int* __restrict__ status) {
+    __shared__ int wtot[SCAN_THREADS / 64];
+    __shared__ int s_base;
+    const int n = real_n(n_dev, n_max);
+    // blocks in front of this one
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_THREADS) part += sums[b];
+    part = wave_reduce_add(part);
+    if (lane_id() == 0) wtot[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) t += wtot[w];
+        s_base = t;
+    }
+    __syncthreads();
+    const int block_base = s_base;
+    // thread t owns SCAN_ITEMS consecutive rows
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int f[SCAN_ITEMS], fr[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int i = base + k;
+        fr[k] = (i < n) ? vals[slot_of_row[i]] : -1;
+        f[k] = (i < n && fr[k] == i) ? 1 : 0;
+        s += f[k];
+    }
+    const int incl = wave_incl_scan_i(s);
+    __syncthreads();
+    if (lane_id() == 63) wtot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+        const int t = wtot[w];
+        if (w < (int)(threadIdx.x >> 6)) woff += t;
+        tot += t;
+    }
+    int ex = block_base + woff + incl - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int i = base + k;
+        if (i < n_max) { newid[i] = ex; first_row[i] = fr[k]; }
+        ex += f[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = (status && *status != 0) ? -1 : block_base + tot;
+}
+
+// unique_index[new] = first row; inverse[i] = new id of i's survivor; survivor coordinates; table value -> new id
+__global__ __launch_bounds__(TPB) void k_unique_write(const int* __restrict__ coords, const int* __restrict__ slot_of_row,
+                                                     const int* __restrict__ first_row, const int* __restrict__ newid,
                                                      const int* n_dev, int n_max, int* __restrict__ unique_index,
-                                                     int* __restrict__ inverse) {
+                                                     int* __restrict__ inverse, int* __restrict__ out_coords,
+                                                     int* __restrict__ vals) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= real_n(n_dev, n_max)) return;
-    if (flags[i]) unique_index[newid[i]] = i;
-    if (inverse) inverse[i] = newid[vals[slot_of_row[i]]];
-}
-
-// table values: first original row -> row id in the de-duplicated set (only slots owned by a first row)
-__global__ __launch_bounds__(TPB) void k_table_renumber(const int* __restrict__ slot_of_row, const int* __restrict__ flags,
-                                                       const int* __restrict__ newid, const int* n_dev, int n_max,
-                                                       int* __restrict__ vals) {
-    const int i = blockIdx.x * TPB + threadIdx.x;
-    if (i >= real_n(n_dev, n_max)) return;
-    if (flags[i]) vals[slot_of_row[i]] = newid[i];
-}
-
-__global__ __launch_bounds__(TPB) void k_gather_coords(const int* __restrict__ coords, const int* __restrict__ unique_index,
-                                                      const int* __restrict__ n_unique, int n_max,
-                                                      int* __restrict__ out_coords) {
-    const int i = blockIdx.x * TPB + threadIdx.x;
-    if (i >= real_n(n_unique, n_max)) return;
-    reinterpret_cast<int4*>(out_coords)[i] = reinterpret_cast<const int4*>(coords)[unique_index[i]];
+    const int first = first_row[i];
+    if (first == i) {
+        const int id = newid[i];
+        unique_index[id] = i;
+        if (out_coords) reinterpret_cast<int4*>(out_coords)[id] = reinterpret_cast<const int4*>(coords)[i];
+        vals[slot_of_row[i]] = id;
+    }
+    if (inverse) inverse[i] = newid[first];
 }
 
 // ---- stride: parent coordinate of every fine row ------------------------------------------------------------------
@@ -121,27 +197,38 @@ __global__ __launch_bounds__(TPB) void k_insert_parents(const int* __restrict__ 
     slot_of_row[i] = table_insert_min(keys, vals, mask, pack4(c.x, px, py, pz), i);
 }
 
-// coarse coords (first-occurrence order), child -> (parent row, k), 8-way child table of the k=2,s=2 convolution
+// coarse coords (first-occurrence order), child -> (parent row, k), 8-way child table of the k=2,s=2 convolution,
+// optionally the transposed table row (nbr_up[i][k] = parent at k = child_k, -1 elsewhere), table value -> coarse row
 __global__ __launch_bounds__(TPB) void k_stride_write(const int* __restrict__ coords, const int* n_dev, int n_max,
                                                      int stride_out, const int* __restrict__ slot_of_row,
-                                                     const int* __restrict__ vals, const int* __restrict__ flags,
-                                                     const int* __restrict__ newid, int* __restrict__ coarse_coords,
+                                                     const int* __restrict__ first_row, const int* __restrict__ newid,
+                                                     int* __restrict__ vals, int* __restrict__ coarse_coords,
                                                      int* __restrict__ parent_row, int* __restrict__ child_k,
-                                                     int* __restrict__ nbr_down) {
+                                                     int* __restrict__ nbr_down, int* __restrict__ nbr_up) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= real_n(n_dev, n_max)) return;
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
     const int s_in = stride_out >> 1;
     const int px = floor_div(c.y, stride_out) * stride_out, py = floor_div(c.z, stride_out) * stride_out,
               pz = floor_div(c.w, stride_out) * stride_out;
-    const int first = vals[slot_of_row[i]];  // still the first child row here
+    const int first = first_row[i];
     const int prow = newid[first];
-    if (flags[i]) reinterpret_cast<int4*>(coarse_coords)[prow] = make_int4(c.x, px, py, pz);
+    if (first == i) {
+        reinterpret_cast<int4*>(coarse_coords)[prow] = make_int4(c.x, px, py, pz);
+        vals[slot_of_row[i]] = prow;
+    }
     // even kernel (K=2): offsets 0..1 per axis, x fastest (ME convention C1/C2)
     const int k = ((c.y - px) / s_in) + 2 * ((c.z - py) / s_in) + 4 * ((c.w - pz) / s_in);
     parent_row[i] = prow;
     child_k[i] = k;
     nbr_down[(size_t)prow * 8 + k] = i;
+    if (nbr_up) {
+        int4 lo = make_int4(-1, -1, -1, -1), hi = lo;
+        int* v = (k < 4) ? &lo.x : &hi.x;
+        v[k & 3] = prow;
+        reinterpret_cast<int4*>(nbr_up)[2 * (size_t)i + 0] = lo;
+        reinterpret_cast<int4*>(nbr_up)[2 * (size_t)i + 1] = hi;
+    }
 }
 
 // ---- kernel map: nbr[row][k] = row of (coords[row] + offsets[k]) in the table, or -1 -----------------------------
@@ -173,10 +260,6 @@ __global__ __launch_bounds__(TPB) void k_up_table(const int* __restrict__ parent
     reinterpret_cast<int4*>(nbr_up)[2 * (size_t)i + 1] = hi;
 }
 
-__global__ void k_set_status(const int* __restrict__ status, int* __restrict__ n_out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && *status != 0) *n_out = -1;
-}
-
 }  // namespace
 }  // namespace pbn
 
@@ -193,15 +276,16 @@ extern "C" size_t pbn_coords_workspace_bytes(int n_max) {
     return 3 * align_up(N * sizeof(int), 256) + align_up(scan_tmp_ints((long long)N) * sizeof(int), 256) + 512;
 }
 
+namespace pbn {
 namespace {
 struct CoordWs {
-    int *slot_of_row, *flags, *newid, *scan_tmp, *status;
+    int *slot_of_row, *first_row, *newid, *scan_tmp, *status;
 };
 bool carve_ws(void* ws, size_t bytes, int n_max, CoordWs& w) {
     Carver cv(ws, bytes);
     const size_t N = (size_t)(n_max > 0 ? n_max : 1);
     w.slot_of_row = cv.take<int>(N);
-    w.flags = cv.take<int>(N);
+    w.first_row = cv.take<int>(N);
     w.newid = cv.take<int>(N);
     w.scan_tmp = cv.take<int>(scan_tmp_ints((long long)N));
     w.status = cv.take<int>(4);
@@ -209,71 +293,89 @@ bool carve_ws(void* ws, size_t bytes, int n_max, CoordWs& w) {
 }
 }  // namespace
 
-extern "C" int pbn_coords_unique(const int32_t* coords, const int32_t* n_dev, int n_max, uint64_t* table_keys,
-                                 int32_t* table_vals, int capacity, int32_t* unique_index, int32_t* inverse,
-                                 int32_t* unique_coords, int32_t* n_unique, void* workspace, size_t workspace_bytes,
-                                 pbn_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// clear = false: the caller has already filled the table (keys 0xff, values 0x7f), nbr_down (0xff) and zeroed the
+// count / status words in bulk (pbn_coords_build does that for a whole pyramid with three memsets).
+int coords_unique_impl(const int32_t* coords, const int32_t* n_dev, int n_max, uint64_t* table_keys, int32_t* table_vals,
+                       int capacity, int32_t* unique_index, int32_t* inverse, int32_t* unique_coords, int32_t* n_unique,
+                       void* workspace, size_t workspace_bytes, int32_t* status, bool clear, hipStream_t stream) {
     if (n_max < 0 || capacity < 1024 || (capacity & (capacity - 1)) || (long long)capacity < 2LL * n_max || !n_unique ||
         !table_keys || !table_vals)
         return PBN_ERR_ARG;
-    PBN_HIP_CHECK(hipMemsetAsync(table_keys, 0xff, sizeof(uint64_t) * (size_t)capacity, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(table_vals, 0x7f, sizeof(int) * (size_t)capacity, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(n_unique, 0, sizeof(int), stream));
+    if (clear) {
+        PBN_HIP_CHECK(hipMemsetAsync(table_keys, 0xff, sizeof(uint64_t) * (size_t)capacity, stream));
+        PBN_HIP_CHECK(hipMemsetAsync(table_vals, 0x7f, sizeof(int) * (size_t)capacity, stream));
+        PBN_HIP_CHECK(hipMemsetAsync(n_unique, 0, sizeof(int), stream));
+    }
     if (n_max == 0) return PBN_OK;
     if (!coords || !unique_index || !workspace) return PBN_ERR_ARG;
     CoordWs w;
     if (!carve_ws(workspace, workspace_bytes, n_max, w)) return PBN_ERR_WORKSPACE;
-    PBN_HIP_CHECK(hipMemsetAsync(w.status, 0, sizeof(int) * 4, stream));
-    const int nb = cdiv(n_max, TPB);
+    if (!status) {
+        status = w.status;
+        PBN_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int) * 4, stream));
+    }
+    const int nb = cdiv(n_max, TPB), nsb = cdiv(n_max, SCAN_TILE);
     const unsigned mask = (unsigned)capacity - 1;
     hipLaunchKernelGGL(k_insert_rows, dim3(nb), dim3(TPB), 0, stream, coords, n_dev, n_max,
-                       (unsigned long long*)table_keys, table_vals, mask, w.slot_of_row, w.status);
-    hipLaunchKernelGGL(k_first_flags, dim3(nb), dim3(TPB), 0, stream, w.slot_of_row, table_vals, n_dev, n_max, w.flags);
-    int rc = scan_exclusive_i32(w.flags, w.newid, n_max, w.scan_tmp, n_unique, stream);
-    if (rc != PBN_OK) return rc;
-    hipLaunchKernelGGL(k_unique_write, dim3(nb), dim3(TPB), 0, stream, w.slot_of_row, table_vals, w.flags, w.newid, n_dev,
-                       n_max, unique_index, inverse);
-    hipLaunchKernelGGL(k_table_renumber, dim3(nb), dim3(TPB), 0, stream, w.slot_of_row, w.flags, w.newid, n_dev, n_max,
-                       table_vals);
-    if (unique_coords)
-        hipLaunchKernelGGL(k_gather_coords, dim3(nb), dim3(TPB), 0, stream, coords, unique_index, n_unique, n_max,
-                           unique_coords);
-    hipLaunchKernelGGL(k_set_status, dim3(1), dim3(64), 0, stream, w.status, n_unique);
+                       (unsigned long long*)table_keys, table_vals, mask, w.slot_of_row, status);
+    hipLaunchKernelGGL(k_flag_block_sums, dim3(nsb), dim3(SCAN_THREADS), 0, stream, w.slot_of_row, table_vals, n_dev,
+                       n_max, w.scan_tmp);
+    hipLaunchKernelGGL(k_flag_number, dim3(nsb), dim3(SCAN_THREADS), 0, stream, w.slot_of_row, table_vals, n_dev, n_max,
+                       w.scan_tmp, w.newid, w.first_row, n_unique, status);
+    hipLaunchKernelGGL(k_unique_write, dim3(nb), dim3(TPB), 0, stream, coords, w.slot_of_row, w.first_row, w.newid, n_dev,
+                       n_max, unique_index, inverse, unique_coords, table_vals);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
+}
+
+int coords_stride_impl(const int32_t* fine_coords, const int32_t* n_fine_dev, int n_fine_max, int stride_out,
+                       uint64_t* table_keys, int32_t* table_vals, int capacity, int32_t* coarse_coords,
+                       int32_t* parent_row, int32_t* child_k, int32_t* nbr_down, int32_t* nbr_up, int32_t* n_coarse,
+                       void* workspace, size_t workspace_bytes, bool clear, hipStream_t stream) {
+    if (n_fine_max < 0 || stride_out < 2 || (stride_out & 1) || capacity < 1024 || (capacity & (capacity - 1)) ||
+        (long long)capacity < 2LL * n_fine_max || !n_coarse || !table_keys || !table_vals)
+        return PBN_ERR_ARG;
+    if (clear) {
+        PBN_HIP_CHECK(hipMemsetAsync(table_keys, 0xff, sizeof(uint64_t) * (size_t)capacity, stream));
+        PBN_HIP_CHECK(hipMemsetAsync(table_vals, 0x7f, sizeof(int) * (size_t)capacity, stream));
+        PBN_HIP_CHECK(hipMemsetAsync(n_coarse, 0, sizeof(int), stream));
+    }
+    if (n_fine_max == 0) return PBN_OK;
+    if (!fine_coords || !coarse_coords || !parent_row || !child_k || !nbr_down || !workspace) return PBN_ERR_ARG;
+    CoordWs w;
+    if (!carve_ws(workspace, workspace_bytes, n_fine_max, w)) return PBN_ERR_WORKSPACE;
+    if (clear) PBN_HIP_CHECK(hipMemsetAsync(nbr_down, 0xff, sizeof(int) * 8 * (size_t)n_fine_max, stream));
+    const int nb = cdiv(n_fine_max, TPB), nsb = cdiv(n_fine_max, SCAN_TILE);
+    const unsigned mask = (unsigned)capacity - 1;
+    hipLaunchKernelGGL(k_insert_parents, dim3(nb), dim3(TPB), 0, stream, fine_coords, n_fine_dev, n_fine_max, stride_out,
+                       (unsigned long long*)table_keys, table_vals, mask, w.slot_of_row);
+    hipLaunchKernelGGL(k_flag_block_sums, dim3(nsb), dim3(SCAN_THREADS), 0, stream, w.slot_of_row, table_vals, n_fine_dev,
+                       n_fine_max, w.scan_tmp);
+    hipLaunchKernelGGL(k_flag_number, dim3(nsb), dim3(SCAN_THREADS), 0, stream, w.slot_of_row, table_vals, n_fine_dev,
+                       n_fine_max, w.scan_tmp, w.newid, w.first_row, n_coarse, (const int*)nullptr);
+    hipLaunchKernelGGL(k_stride_write, dim3(nb), dim3(TPB), 0, stream, fine_coords, n_fine_dev, n_fine_max, stride_out,
+                       w.slot_of_row, w.first_row, w.newid, table_vals, coarse_coords, parent_row, child_k, nbr_down,
+                       nbr_up);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+}  // namespace pbn
+
+extern "C" int pbn_coords_unique(const int32_t* coords, const int32_t* n_dev, int n_max, uint64_t* table_keys,
+                                 int32_t* table_vals, int capacity, int32_t* unique_index, int32_t* inverse,
+                                 int32_t* unique_coords, int32_t* n_unique, void* workspace, size_t workspace_bytes,
+                                 pbn_stream_t stream_) {
+    return coords_unique_impl(coords, n_dev, n_max, table_keys, table_vals, capacity, unique_index, inverse, unique_coords,
+                              n_unique, workspace, workspace_bytes, nullptr, true, (hipStream_t)stream_);
 }
 
 extern "C" int pbn_coords_stride(const int32_t* fine_coords, const int32_t* n_fine_dev, int n_fine_max, int stride_out,
                                  uint64_t* table_keys, int32_t* table_vals, int capacity, int32_t* coarse_coords,
                                  int32_t* parent_row, int32_t* child_k, int32_t* nbr_down, int32_t* n_coarse,
                                  void* workspace, size_t workspace_bytes, pbn_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (n_fine_max < 0 || stride_out < 2 || (stride_out & 1) || capacity < 1024 || (capacity & (capacity - 1)) ||
-        (long long)capacity < 2LL * n_fine_max || !n_coarse || !table_keys || !table_vals)
-        return PBN_ERR_ARG;
-    PBN_HIP_CHECK(hipMemsetAsync(table_keys, 0xff, sizeof(uint64_t) * (size_t)capacity, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(table_vals, 0x7f, sizeof(int) * (size_t)capacity, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(n_coarse, 0, sizeof(int), stream));
-    if (n_fine_max == 0) return PBN_OK;
-    if (!fine_coords || !coarse_coords || !parent_row || !child_k || !nbr_down || !workspace) return PBN_ERR_ARG;
-    CoordWs w;
-    if (!carve_ws(workspace, workspace_bytes, n_fine_max, w)) return PBN_ERR_WORKSPACE;
-    PBN_HIP_CHECK(hipMemsetAsync(nbr_down, 0xff, sizeof(int) * 8 * (size_t)n_fine_max, stream));
-    const int nb = cdiv(n_fine_max, TPB);
-    const unsigned mask = (unsigned)capacity - 1;
-    hipLaunchKernelGGL(k_insert_parents, dim3(nb), dim3(TPB), 0, stream, fine_coords, n_fine_dev, n_fine_max, stride_out,
-                       (unsigned long long*)table_keys, table_vals, mask, w.slot_of_row);
-    hipLaunchKernelGGL(k_first_flags, dim3(nb), dim3(TPB), 0, stream, w.slot_of_row, table_vals, n_fine_dev, n_fine_max,
-                       w.flags);
-    int rc = scan_exclusive_i32(w.flags, w.newid, n_fine_max, w.scan_tmp, n_coarse, stream);
-    if (rc != PBN_OK) return rc;
-    hipLaunchKernelGGL(k_stride_write, dim3(nb), dim3(TPB), 0, stream, fine_coords, n_fine_dev, n_fine_max, stride_out,
-                       w.slot_of_row, table_vals, w.flags, w.newid, coarse_coords, parent_row, child_k, nbr_down);
-    hipLaunchKernelGGL(k_table_renumber, dim3(nb), dim3(TPB), 0, stream, w.slot_of_row, w.flags, w.newid, n_fine_dev,
-                       n_fine_max, table_vals);
-    PBN_LAUNCH_CHECK();
-    return PBN_OK;
+    return coords_stride_impl(fine_coords, n_fine_dev, n_fine_max, stride_out, table_keys, table_vals, capacity,
+                              coarse_coords, parent_row, child_k, nbr_down, nullptr, n_coarse, workspace, workspace_bytes,
+                              true, (hipStream_t)stream_);
 }
 
 extern "C" int pbn_kernel_map(const int32_t* out_coords, const int32_t* n_out_dev, int n_out_max, const int32_t* offsets,

@@ -18,20 +18,23 @@ extern "C" size_t pbn_coords_arena_bytes(int n, int want_k5, pbn_coords_layout* 
     const int cap = pbn_hash_capacity(n);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = a256(off + bytes); return (int64_t)o; };
-    L->counts = take(8 * sizeof(int));
+    // fill-pattern groups are contiguous so that pbn_coords_build clears a whole pyramid with three memsets:
+    //   [counts + status: 0x00] [keys of 5 levels, nbr_down of 4 levels: 0xff] [values of 5 levels: 0x7f]
+    L->counts = take(16 * sizeof(int));                      // 5 row counts, [8] = range-error status
+    for (int l = 0; l < 5; ++l) { L->capacity[l] = cap; L->keys[l] = take((size_t)cap * 8); }
+    for (int l = 0; l < 4; ++l) L->nbr_down[l] = take(N * 8 * 4);
+    for (int l = 0; l < 5; ++l) L->vals[l] = take((size_t)cap * 4);
+    const int64_t fill_end = (int64_t)off;
+    (void)fill_end;
     L->unique_index = take(N * 4);
     L->inverse = take(N * 4);
     for (int l = 0; l < 5; ++l) {
-        L->capacity[l] = cap;
-        L->keys[l] = take((size_t)cap * 8);
-        L->vals[l] = take((size_t)cap * 4);
         L->coords[l] = take(N * 16);
         L->k3[l] = take(N * 27 * 4);
     }
     for (int l = 0; l < 4; ++l) {
         L->parent_row[l] = take(N * 4);
         L->child_k[l] = take(N * 4);
-        L->nbr_down[l] = take(N * 8 * 4);
         L->up[l] = take(N * 8 * 4);
     }
     L->k5 = want_k5 ? take(N * 125 * 4) : -1;
@@ -50,13 +53,18 @@ extern "C" int pbn_coords_build(const int32_t* coords, const int32_t* n_dev, int
     int32_t* counts = I(L->counts);
     void* ws = A + L->workspace;
     const size_t wsb = (size_t)L->workspace_bytes;
-    int rc = pbn_coords_unique(coords, n_dev, n, (uint64_t*)(A + L->keys[0]), I(L->vals[0]), L->capacity[0],
-                               I(L->unique_index), I(L->inverse), I(L->coords[0]), counts + 0, ws, wsb, stream);
+    hipStream_t st = (hipStream_t)stream;
+    PBN_HIP_CHECK(hipMemsetAsync(A + L->counts, 0, 16 * sizeof(int), st));
+    PBN_HIP_CHECK(hipMemsetAsync(A + L->keys[0], 0xff, (size_t)(L->vals[0] - L->keys[0]), st));
+    PBN_HIP_CHECK(hipMemsetAsync(A + L->vals[0], 0x7f, (size_t)(L->unique_index - L->vals[0]), st));
+    int rc = coords_unique_impl(coords, n_dev, n, (uint64_t*)(A + L->keys[0]), I(L->vals[0]), L->capacity[0],
+                                I(L->unique_index), I(L->inverse), I(L->coords[0]), counts + 0, ws, wsb, counts + 8, false,
+                                st);
     if (rc != PBN_OK) return rc;
     for (int l = 0; l < 4; ++l) {
-        rc = pbn_coords_stride(I(L->coords[l]), counts + l, n, 2 << l, (uint64_t*)(A + L->keys[l + 1]), I(L->vals[l + 1]),
-                               L->capacity[l + 1], I(L->coords[l + 1]), I(L->parent_row[l]), I(L->child_k[l]),
-                               I(L->nbr_down[l]), counts + l + 1, ws, wsb, stream);
+        rc = coords_stride_impl(I(L->coords[l]), counts + l, n, 2 << l, (uint64_t*)(A + L->keys[l + 1]), I(L->vals[l + 1]),
+                                L->capacity[l + 1], I(L->coords[l + 1]), I(L->parent_row[l]), I(L->child_k[l]),
+                                I(L->nbr_down[l]), I(L->up[l]), counts + l + 1, ws, wsb, false, st);
         if (rc != PBN_OK) return rc;
     }
     for (int l = 0; l < 5; ++l) {
@@ -67,10 +75,6 @@ extern "C" int pbn_coords_build(const int32_t* coords, const int32_t* n_dev, int
     if (want_k5) {
         rc = pbn_kernel_map_cube(I(L->coords[0]), counts + 0, n, 5, 1, x_fastest, (const uint64_t*)(A + L->keys[0]),
                                  I(L->vals[0]), L->capacity[0], I(L->k5), stream);
-        if (rc != PBN_OK) return rc;
-    }
-    for (int l = 0; l < 4; ++l) {
-        rc = pbn_up_table(I(L->parent_row[l]), I(L->child_k[l]), counts + l, n, I(L->up[l]), stream);
         if (rc != PBN_OK) return rc;
     }
     return PBN_OK;

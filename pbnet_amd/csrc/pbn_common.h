@@ -69,4 +69,13 @@ static inline size_t scan_tmp_ints(long long n) { return (size_t)cdiv(n, SCAN_TI
 // out[i] = sum_{j<i} in[j] for i in [0,n); if total != nullptr, *total = sum of all.  in may alias out.
 int scan_exclusive_i32(const int* in, int* out, int n, int* tmp, int* total, hipStream_t stream);
 
+// coords.hip internals shared with executor.hip (see the definitions for the `clear` contract)
+int coords_unique_impl(const int32_t* coords, const int32_t* n_dev, int n_max, uint64_t* table_keys, int32_t* table_vals,
+                       int capacity, int32_t* unique_index, int32_t* inverse, int32_t* unique_coords, int32_t* n_unique,
+                       void* workspace, size_t workspace_bytes, int32_t* status, bool clear, hipStream_t stream);
+int coords_stride_impl(const int32_t* fine_coords, const int32_t* n_fine_dev, int n_fine_max, int stride_out,
+                       uint64_t* table_keys, int32_t* table_vals, int capacity, int32_t* coarse_coords,
+                       int32_t* parent_row, int32_t* child_k, int32_t* nbr_down, int32_t* nbr_up, int32_t* n_coarse,
+                       void* workspace, size_t workspace_bytes, bool clear, hipStream_t stream);
+
 }  // namespace pbn

@@ -11,6 +11,8 @@ Two execution paths over the same parameters:
     block stores its result directly into the right-hand columns of the decoder's concat slab, the transposed
     convolution into the left-hand columns), so no activation is touched twice.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -41,7 +43,7 @@ _UP_BN = ("bntr4", "bntr5", "bntr6", "bntr7")
 
 class MinkUNet(nn.Module):
     FUSE_EVAL = True
-    MORTON = True           # fused path runs the lineage in Z-order (bit-identical outputs, better tiles)
+    MORTON = os.environ.get("PBNET_MORTON", "1") != "0"   # fused path runs the lineage in Z-order (L2-local gathers)
     OP_TIMING_SINK = None   # callable(model, plan, rows, cm, esz, op_ms) installed by bench.py's roofline probe
 
     def __init__(self, in_channels, out_channels, D=3, arch="MinkUNet34C"):
