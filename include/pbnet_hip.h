@@ -175,6 +175,28 @@ int pbn_segment_pool(const void* feats, int ld, int channels, int dtype, const i
                      float* out_max, float* out_avg, void* workspace, size_t workspace_bytes, pbn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Stage glue of PBNet.forward (csrc/stages.hip): each call replaces a run of small tensor ops of the reference by one
+ * launch with identical integer results and the same fp32 arithmetic.
+ *
+ * pbn_local_scene_rows -- rows of every local scene (network/PBNet.py:182-247).  Entry e (one grouping cluster taking
+ * part in one local scene) owns rows [ent_row_start[e], ent_row_start[e+1]); row j of it is the point
+ * ins_ind[member_idx[ent_member_start[e] + j]].  Per row: point_idx, row_scene = ent_scene[e], the mask-branch voxel
+ * coordinate (scene, floor(xyz * inv_voxel)) -- the reference divides a device tensor by a host scalar, which is a
+ * multiplication by the fp32 reciprocal -- and the mask-branch input row
+ *   [point_feat[p, 0:channels], sem_score[p, sem_pred[p]], ent_weight[e], 0 ... 0]   (ld_out elements of `dtype`).
+ *
+ * pbn_gather_pad_rows -- out[i, 0:row_bytes] = in[idx[i], 0:row_bytes] (idx NULL = identity), the rest of the output
+ * row zero-filled: builds a 16-byte-aligned, zero-padded input slab in one pass.  All byte counts multiples of 4. */
+int pbn_local_scene_rows(const int32_t* ent_row_start, const int32_t* ent_member_start, const int32_t* ent_scene,
+                         const float* ent_weight, int n_ent, int n_rows, const int32_t* member_idx,
+                         const int64_t* ins_ind, const float* xyz, float inv_voxel, const void* point_feat, int ld_feat,
+                         int channels, const void* sem_score, int ld_sem, const int64_t* sem_pred, int dtype,
+                         int64_t* point_idx, int64_t* row_scene, int32_t* coords, void* feat_out, int ld_out,
+                         pbn_stream_t stream);
+int pbn_gather_pad_rows(const void* in, int ld_in_bytes, int row_bytes, const int64_t* idx, int n, void* out,
+                        int ld_out_bytes, pbn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * One-call sub-pipelines (csrc/executor.hip): they only sequence the entry points above.
  *
  * pbn_coords_build: everything a MinkUNet needs from one coordinate lineage -- de-duplication, the four coarser

@@ -67,6 +67,9 @@ SIGNATURES = {
     "pbn_gather_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "pbn_segment_pool_workspace_bytes": (c_size, [c_int, c_int]),
     "pbn_segment_pool": (c_int, [c_vp, c_int, c_int, c_int, c_i32p, c_int, c_f32p, c_f32p, c_vp, c_size, c_vp]),
+    "pbn_local_scene_rows": (c_int, [c_i32p, c_i32p, c_i32p, c_f32p, c_int, c_int, c_i32p, c_vp, c_f32p, c_float, c_vp,
+                                     c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i32p, c_vp, c_int, c_vp]),
+    "pbn_gather_pad_rows": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
     "pbn_kernel_map_cube": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_coords_arena_bytes": (c_size, [c_int, c_int, ctypes.POINTER(CoordsLayout)]),
     "pbn_coords_build": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(CoordsLayout), c_vp]),

@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from .. import MinkowskiEngine as ME
 from .. import pbnet_ops
+from .. import stage_ops
 from ..prof import section
 from .Mink import Mink_unet as unet3d
 
@@ -199,31 +200,45 @@ class PBNet(nn.Module):
         _sec = section("a17_gather"); _sec.__enter__()
         ent_cluster_t = torch.tensor(ent_cluster, dtype=torch.long)
         ent_rows = sizes[ent_cluster_t]
-        ent_scene = torch.repeat_interleave(torch.arange(len(scene_len)), torch.tensor(scene_len))
-        d = lambda t: t.to(dev)
-        row_ent = torch.repeat_interleave(torch.arange(len(ent_cluster), device=dev), d(ent_rows))
-        ent_first = d(torch.cumsum(ent_rows, 0) - ent_rows)
-        pos_in_ent = torch.arange(row_ent.shape[0], device=dev) - ent_first[row_ent]
-        member_pos = d(member_start[:-1][ent_cluster_t])[row_ent] + pos_in_ent
-        local_idx = res.member_idx[member_pos].long()                            # index into the grouped array
-        point_idx = ins_ind[local_idx]                                           # index into the scene's points
-        row_scene = d(ent_scene)[row_ent]
-        row_weight = d(torch.tensor(ent_weight, dtype=torch.float32))[row_ent]
-        row_sem_sf = sem_sfp[point_idx, sem_pred_p[point_idx]]                    # PBNet.py:162-163: own-class score
-        feat = torch.cat([point_feat_p[point_idx], row_sem_sf.view(-1, 1).to(point_feat_p.dtype),
-                          row_weight.view(-1, 1).to(point_feat_p.dtype)], 1)     # [R, 34]  PBNet.py:194,230
+        if not torch.is_grad_enabled():
+            # inference: ONE launch (pbn_local_scene_rows) driven by one packed host->device copy of the entry table
+            n_ent = len(ent_cluster)
+            row_start = torch.zeros(n_ent + 1, dtype=torch.int32)
+            row_start[1:] = torch.cumsum(ent_rows, 0)
+            n_rows = int(row_start[-1])
+            ent_scene = torch.repeat_interleave(torch.arange(len(scene_len), dtype=torch.int32),
+                                                torch.tensor(scene_len))
+            packed = torch.cat([row_start, member_start[:-1][ent_cluster_t].to(torch.int32), ent_scene,
+                                torch.tensor(ent_weight, dtype=torch.float32).view(torch.int32)]).to(dev)
+            point_idx, row_scene, coords, feat = stage_ops.local_scene_rows(
+                packed, n_ent, n_rows, res.member_idx, ins_ind, xyz_original, LOCAL_VOXEL, point_feat_p, sem_sfp,
+                sem_pred_p)
+        else:
+            ent_scene = torch.repeat_interleave(torch.arange(len(scene_len)), torch.tensor(scene_len))
+            d = lambda t: t.to(dev)
+            row_ent = torch.repeat_interleave(torch.arange(len(ent_cluster), device=dev), d(ent_rows))
+            ent_first = d(torch.cumsum(ent_rows, 0) - ent_rows)
+            pos_in_ent = torch.arange(row_ent.shape[0], device=dev) - ent_first[row_ent]
+            member_pos = d(member_start[:-1][ent_cluster_t])[row_ent] + pos_in_ent
+            local_idx = res.member_idx[member_pos].long()                            # index into the grouped array
+            point_idx = ins_ind[local_idx]                                           # index into the scene's points
+            row_scene = d(ent_scene)[row_ent]
+            row_weight = d(torch.tensor(ent_weight, dtype=torch.float32))[row_ent]
+            row_sem_sf = sem_sfp[point_idx, sem_pred_p[point_idx]]                    # PBNet.py:162-163: own-class score
+            feat = torch.cat([point_feat_p[point_idx], row_sem_sf.view(-1, 1).to(point_feat_p.dtype),
+                              row_weight.view(-1, 1).to(point_feat_p.dtype)], 1)     # [R, 34]  PBNet.py:194,230
+            coords = torch.cat([row_scene.view(-1, 1).to(torch.int32),
+                                torch.floor(xyz_original[point_idx] / LOCAL_VOXEL).to(torch.int32)], 1)
         out = {}
         _sec.__exit__(None, None, None)
 
         # (a18) mask branch
         with section("a18_mask_coords"):
-            coords = torch.cat([row_scene.view(-1, 1).to(torch.int32),
-                                torch.floor(xyz_original[point_idx] / LOCAL_VOXEL).to(torch.int32)], 1)
             inputs_v2 = ME.SparseTensor(feat, coords)
         with section("a18_mask_unet"):
             mask_score = self.linear_binary(self.D_Unet(inputs_v2)).F[inputs_v2.inverse_mapping]   # [R, 1]
         if task != "test":
-            gt_rows = d(torch.tensor(scene_gt, dtype=torch.long))[row_scene]
+            gt_rows = torch.tensor(scene_gt, dtype=torch.long).to(dev)[row_scene]
             lab = ins_label[point_idx]
             gt_mask = (lab == gt_rows).long()
             gt_mask[lab == -100] = -1

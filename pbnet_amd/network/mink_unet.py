@@ -231,8 +231,19 @@ class MinkUNet(nn.Module):
         cin_p = plan["cin_p"]
         if sv is not None or feats.shape[1] < cin_p or feats.stride(1) != 1 \
                 or (feats.stride(0) * feats.element_size()) % 16 or feats.data_ptr() % 16:
-            padded = torch.zeros(feats.shape[0], cin_p, dtype=dt, device=dev)
-            padded[:, :feats.shape[1]] = feats if sv is None else feats[sv.perm]
+            es = feats.element_size()
+            if feats.stride(1) == 1 and (feats.shape[1] * es) % 4 == 0 and (feats.stride(0) * es) % 4 == 0 \
+                    and feats.data_ptr() % 4 == 0:
+                # one pass: rows in Z-order (or as they are), zero-padded to whole 16-byte vectors
+                n_in = int(feats.shape[0]) if sv is None else int(sv.perm.shape[0])
+                padded = torch.empty(n_in, cin_p, dtype=dt, device=dev)
+                N.check(N.lib().pbn_gather_pad_rows(
+                    ctypes.c_void_p(feats.data_ptr()), feats.stride(0) * es, feats.shape[1] * es,
+                    None if sv is None else ctypes.c_void_p(sv.perm.data_ptr()), n_in, ctypes.c_void_p(padded.data_ptr()),
+                    cin_p * es, N.current_stream()), "pbn_gather_pad_rows")
+            else:
+                padded = torch.zeros(feats.shape[0], cin_p, dtype=dt, device=dev)
+                padded[:, :feats.shape[1]] = feats if sv is None else feats[sv.perm]
             feats = padded
         rows = list(pyr.n)
         n_rows = (ctypes.c_int32 * 5)(*rows)

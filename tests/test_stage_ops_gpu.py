@@ -1,0 +1,79 @@
+"""GPU tier: the fused stage-glue launches (csrc/stages.hip) against the tensor-op form they replace
+(/root/reference/network/PBNet.py:182-247 and friends).  Integer outputs bit-exact; feature rows bit-exact (copies)."""
+import numpy as np
+import pytest
+import torch
+
+from pbnet_amd import stage_ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _entries(rng, n_clusters, sizes, n_scenes):
+    """Random local-scene plan: each scene = 1..4 entries (clusters, possibly repeated across scenes)."""
+    ent_cluster, ent_weight, scene_len = [], [], []
+    for _ in range(n_scenes):
+        k = int(rng.integers(1, 5))
+        scene_len.append(k)
+        for j in range(k):
+            ent_cluster.append(int(rng.integers(0, n_clusters)))
+            ent_weight.append(1.0 if j == 0 else float(rng.uniform(0.05, 0.5)))
+    return ent_cluster, ent_weight, scene_len
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_local_scene_rows_matches_tensor_ops(dtype):
+    rng = np.random.default_rng(3)
+    n_points, m, n_clusters, c, n_cls = 5000, 3000, 37, 32, 20
+    sizes = rng.integers(1, 120, n_clusters)
+    sizes[5] = 700                                              # one long cluster
+    member_start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    total = int(member_start[-1])
+    member_idx = rng.integers(0, m, total).astype(np.int32)
+    ins_ind = torch.from_numpy(rng.permutation(n_points)[:m].astype(np.int64)).to(DEV)
+    xyz = torch.from_numpy(rng.uniform(-3, 6, (n_points, 3)).astype(np.float32)).to(DEV)
+    point_feat = torch.randn(n_points, c, device=DEV).to(dtype)
+    sem_score = torch.softmax(torch.randn(n_points, n_cls, device=DEV), 1).to(dtype)
+    sem_pred = sem_score.float().max(1)[1]
+    ent_cluster, ent_weight, scene_len = _entries(rng, n_clusters, sizes, 23)
+    ec = torch.tensor(ent_cluster, dtype=torch.long)
+    ent_rows = torch.from_numpy(sizes.astype(np.int64))[ec]
+    n_ent = len(ent_cluster)
+    row_start = torch.zeros(n_ent + 1, dtype=torch.int32)
+    row_start[1:] = torch.cumsum(ent_rows, 0)
+    n_rows = int(row_start[-1])
+    ent_scene = torch.repeat_interleave(torch.arange(len(scene_len), dtype=torch.int32), torch.tensor(scene_len))
+    ms = torch.from_numpy(member_start)
+    packed = torch.cat([row_start, ms[:-1][ec].to(torch.int32), ent_scene,
+                        torch.tensor(ent_weight, dtype=torch.float32).view(torch.int32)]).to(DEV)
+    midx = torch.from_numpy(member_idx).to(DEV)
+    voxel = 0.02
+    point_idx, row_scene, coords, feat = stage_ops.local_scene_rows(packed, n_ent, n_rows, midx, ins_ind, xyz, voxel,
+                                                                   point_feat, sem_score, sem_pred)
+    # tensor-op form (what PBNet.forward does with autograd enabled)
+    row_ent = torch.repeat_interleave(torch.arange(n_ent, device=DEV), ent_rows.to(DEV))
+    ent_first = (torch.cumsum(ent_rows, 0) - ent_rows).to(DEV)
+    pos = torch.arange(n_rows, device=DEV) - ent_first[row_ent]
+    want_p = ins_ind[midx[ms[:-1][ec].to(DEV)[row_ent] + pos].long()]
+    want_scene = ent_scene.to(DEV).long()[row_ent]
+    want_w = torch.tensor(ent_weight, dtype=torch.float32, device=DEV)[row_ent]
+    want_feat = torch.cat([point_feat[want_p], sem_score[want_p, sem_pred[want_p]].view(-1, 1),
+                           want_w.view(-1, 1).to(dtype)], 1)
+    want_coords = torch.cat([want_scene.view(-1, 1).to(torch.int32), torch.floor(xyz[want_p] / voxel).to(torch.int32)], 1)
+    assert torch.equal(point_idx, want_p)
+    assert torch.equal(row_scene, want_scene)
+    assert torch.equal(coords, want_coords)
+    assert torch.equal(feat.view(torch.uint8), want_feat.contiguous().view(torch.uint8))
+
+
+def test_gather_pad_rows():
+    from pbnet_amd import _native as N
+    import ctypes
+    x = torch.randn(1000, 34, device=DEV).to(torch.bfloat16)
+    idx = torch.randperm(1000, device=DEV)[:777]
+    out = torch.empty(777, 40, dtype=torch.bfloat16, device=DEV)
+    rc = N.lib().pbn_gather_pad_rows(ctypes.c_void_p(x.data_ptr()), 68, 68, ctypes.c_void_p(idx.data_ptr()), 777,
+                                     ctypes.c_void_p(out.data_ptr()), 80, N.current_stream())
+    assert rc == 0
+    assert torch.equal(out[:, :34], x[idx]) and (out[:, 34:] == 0).all()
