@@ -183,7 +183,8 @@ int pbn_segment_pool(const void* feats, int ld, int channels, int dtype, const i
  * ins_ind[member_idx[ent_member_start[e] + j]].  Per row: point_idx, row_scene = ent_scene[e], the mask-branch voxel
  * coordinate (scene, floor(xyz * inv_voxel)) -- the reference divides a device tensor by a host scalar, which is a
  * multiplication by the fp32 reciprocal -- and the mask-branch input row
- *   [point_feat[p, 0:channels], sem_score[p, sem_pred[p]], ent_weight[e], 0 ... 0]   (ld_out elements of `dtype`).
+ *   [point_feat[p, 0:channels], sem_score[p, sem_pred[p]], ent_weight[e], 0 ... 0]   (ld_out elements of `dtype`);
+ * sem_pred NULL = column 0 (sem_score is then the per-point own-class score of pbn_sem_argmax_table).
  *
  * pbn_gather_pad_rows -- out[i, 0:row_bytes] = in[idx[i], 0:row_bytes] (idx NULL = identity), the rest of the output
  * row zero-filled: builds a 16-byte-aligned, zero-padded input slab in one pass.  All byte counts multiples of 4. */
@@ -195,6 +196,32 @@ int pbn_local_scene_rows(const int32_t* ent_row_start, const int32_t* ent_member
                          pbn_stream_t stream);
 int pbn_gather_pad_rows(const void* in, int ld_in_bytes, int row_bytes, const int64_t* idx, int n, void* out,
                         int ld_out_bytes, pbn_stream_t stream);
+
+/* pbn_mlp_rows -- the two-layer heads of network/PBNet.py:43-82 in eval mode, one launch per head:
+ *   out[i, 0:n_out] = act( W2 . prelu( (W1 . x) * scale + shift ) + b2 ),   x = in[row(i), 0:channels],
+ *   row(i) = idx_b[idx_a[i]] (either index level may be NULL), act = sigmoid or identity.
+ * W1 f32[hidden, channels], scale/shift = eval-mode BatchNorm folded (f32[hidden]), slope f32[hidden] (PReLU),
+ * W2 f32[n_out, hidden], b2 f32[n_out] or NULL.  fp32 arithmetic, one rounding to `dtype` at the end.
+ * channels must be 32 and hidden 16 or 32 (the shapes PBNet builds); anything else returns PBN_ERR_UNSUPPORTED. */
+int pbn_mlp_rows(const void* in, int ld_in, int channels, const int64_t* idx_a, const int64_t* idx_b, int n,
+                 const float* w1, const float* scale, const float* shift, const float* slope, int hidden, const float* w2,
+                 const float* b2, int n_out, int sigmoid, void* out, int ld_out, int dtype, pbn_stream_t stream);
+
+/* pbn_sem_argmax_table -- network/PBNet.py:134,151-163: per point the arg-max class (first maximum), the softmax score
+ * of that class (1 / sum exp(s - max), fp32, rounded to `dtype`; may be NULL) and the [n_cls, nb] population table
+ * (zeroed here; points whose batch index is outside [0, nb) are not counted).  block_hist int32[pbn_select_blocks(n),
+ * n_cls] receives the per-block class histogram pbn_select_points needs.
+ *
+ * pbn_select_points -- network/PBNet.py:151-170: the points of the kept classes in class-major order, ascending point
+ * index inside a class (what a stable sort by class yields), written straight to the grouping inputs:
+ *   position(i) = class_base[c] + #(j < i with class c);   class_base[c] < 0 drops the class.
+ *   ins_ind[pos] = i, ins_orig[pos] = xyz[i], ins_off[pos] = xyz[i] + float(offset[i]) (fp32 add), ins_sem[pos] = c. */
+int pbn_select_blocks(int n);
+int pbn_sem_argmax_table(const void* score, int ld, int n_cls, const int32_t* batch, int nb, int n, int dtype,
+                         int64_t* sem_pred, void* sem_prob, int32_t* table, int32_t* block_hist, pbn_stream_t stream);
+int pbn_select_points(const int64_t* sem_pred, int n, int n_cls, const int32_t* class_base, const int32_t* block_hist,
+                      const float* xyz, const void* offset, int ld_off, int dtype, int64_t* ins_ind, float* ins_orig,
+                      float* ins_off, int32_t* ins_sem, pbn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * One-call sub-pipelines (csrc/executor.hip): they only sequence the entry points above.

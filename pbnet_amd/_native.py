@@ -70,6 +70,12 @@ SIGNATURES = {
     "pbn_local_scene_rows": (c_int, [c_i32p, c_i32p, c_i32p, c_f32p, c_int, c_int, c_i32p, c_vp, c_f32p, c_float, c_vp,
                                      c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i32p, c_vp, c_int, c_vp]),
     "pbn_gather_pad_rows": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
+    "pbn_mlp_rows": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p,
+                             c_int, c_int, c_vp, c_int, c_int, c_vp]),
+    "pbn_select_blocks": (c_int, [c_int]),
+    "pbn_sem_argmax_table": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_int, c_int, c_vp, c_vp, c_i32p, c_i32p, c_vp]),
+    "pbn_select_points": (c_int, [c_vp, c_int, c_int, c_i32p, c_i32p, c_f32p, c_vp, c_int, c_int, c_vp, c_f32p, c_f32p,
+                                  c_i32p, c_vp]),
     "pbn_kernel_map_cube": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_coords_arena_bytes": (c_size, [c_int, c_int, ctypes.POINTER(CoordsLayout)]),
     "pbn_coords_build": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(CoordsLayout), c_vp]),

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(TPB) void k_local_scene_rows(
             if (ESZ == 4) bits = *reinterpret_cast<const unsigned*>(point_feat + ((size_t)p * ld_feat + c) * 4);
             else bits = *reinterpret_cast<const unsigned short*>(point_feat + ((size_t)p * ld_feat + c) * 2);
         } else if (c == channels) {
-            const size_t o = (size_t)p * ld_sem + (size_t)sem_pred[p];
+            const size_t o = (size_t)p * ld_sem + (sem_pred ? (size_t)sem_pred[p] : 0);
             if (ESZ == 4) bits = *reinterpret_cast<const unsigned*>(sem_score + o * 4);
             else bits = *reinterpret_cast<const unsigned short*>(sem_score + o * 2);
         } else if (c == channels + 1) {
@@ -84,6 +84,194 @@ __global__ __launch_bounds__(TPB) void k_gather_pad_rows(const unsigned* __restr
     out[e] = v;
 }
 
+
+// ---- two-layer head: out = act(W2 . prelu(bn(W1 . x)) + b2) per row (PBNet.py:43-82 heads, eval mode) ----------------
+// One thread per output row; the row is read through up to two index levels (row = idx_b[idx_a[i]]), so "gather the
+// voxel features to the points" and "undo the Z-order" cost nothing extra.  All arithmetic in fp32, weights are uniform
+// (scalar loads), one rounding at the end.
+template <typename T> struct RowIO;
+template <> struct RowIO<float> {
+    static constexpr int E = 4;
+    static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct RowIO<__hip_bfloat16> {
+    static constexpr int E = 8;
+    static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+};
+template <> struct RowIO<__half> {
+    static constexpr int E = 8;
+    static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 t = __half22float2(__builtin_bit_cast(__half2, w[i]));
+            f[2 * i] = t.x; f[2 * i + 1] = t.y;
+        }
+    }
+    static __device__ __forceinline__ void store(__half* p, float v) { *p = __float2half(v); }
+};
+
+template <typename T, int C, int H>
+__global__ __launch_bounds__(TPB) void k_mlp_rows(const T* __restrict__ in, int ld_in, const long long* __restrict__ idx_a,
+                                                 const long long* __restrict__ idx_b, int n,
+                                                 const float* __restrict__ w1, const float* __restrict__ scale,
+                                                 const float* __restrict__ shift, const float* __restrict__ slope,
+                                                 const float* __restrict__ w2, const float* __restrict__ b2, int n_out,
+                                                 int sigmoid, T* __restrict__ out, int ld_out) {
+    constexpr int E = RowIO<T>::E;
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    long long row = idx_a ? idx_a[i] : i;
+    if (idx_b) row = idx_b[row];
+    float x[C];
+    const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)row * ld_in);
+#pragma unroll
+    for (int v = 0; v < C / E; ++v) RowIO<T>::unpack(src[v], x + v * E);
+    float h[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) a = fmaf(w1[k * C + c], x[c], a);
+        a = fmaf(a, scale[k], shift[k]);
+        h[k] = a >= 0.f ? a : a * slope[k];
+    }
+    for (int o = 0; o < n_out; ++o) {
+        float a = b2 ? b2[o] : 0.f;
+#pragma unroll
+        for (int k = 0; k < H; ++k) a = fmaf(w2[o * H + k], h[k], a);
+        if (sigmoid) a = 1.0f / (1.0f + expf(-a));
+        RowIO<T>::store(out + (size_t)i * ld_out + o, a);
+    }
+}
+
+// ---- semantic argmax + own-class softmax score + [class, batch] population table (PBNet.py:134,151-163) -------------
+// Block = SEL_BLOCK consecutive points.  Besides the global table it leaves the per-block class histogram that
+// k_select_points turns into stable output positions.
+constexpr int SEL_BLOCK = 1024;
+constexpr int SEL_MAX_CLASSES = 32;
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void k_sem_argmax_table(const T* __restrict__ score, int ld, int n_cls,
+                                                         const int* __restrict__ batch, int nb, int n,
+                                                         long long* __restrict__ sem_pred, T* __restrict__ sem_prob,
+                                                         int* __restrict__ table, int* __restrict__ block_hist) {
+    __shared__ int s_tab[SEL_MAX_CLASSES * 8];
+    __shared__ int s_cls[SEL_MAX_CLASSES];
+    for (int e = threadIdx.x; e < n_cls * nb; e += TPB) s_tab[e] = 0;
+    if (threadIdx.x < n_cls) s_cls[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * SEL_BLOCK;
+    for (int k = 0; k < SEL_BLOCK / TPB; ++k) {
+        const int i = base + k * TPB + threadIdx.x;
+        if (i >= n) break;
+        const T* s = score + (size_t)i * ld;
+        float best = -__builtin_inff();
+        int arg = 0;
+        for (int c = 0; c < n_cls; ++c) {
+            float v;
+            if constexpr (sizeof(T) == 4) v = s[c];
+            else if constexpr (__is_same(T, __hip_bfloat16)) v = __bfloat162float(s[c]);
+            else v = __half2float(s[c]);
+            if (v > best) { best = v; arg = c; }       // first maximum wins
+        }
+        float sum = 0.f;
+        for (int c = 0; c < n_cls; ++c) {
+            float v;
+            if constexpr (sizeof(T) == 4) v = s[c];
+            else if constexpr (__is_same(T, __hip_bfloat16)) v = __bfloat162float(s[c]);
+            else v = __half2float(s[c]);
+            sum += expf(v - best);
+        }
+        sem_pred[i] = arg;
+        if (sem_prob) RowIO<T>::store(sem_prob + i, 1.0f / sum);
+        atomicAdd(&s_cls[arg], 1);
+        const int b = batch ? batch[i] : 0;
+        if (b >= 0 && b < nb) atomicAdd(&s_tab[arg * nb + b], 1);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_cls * nb; e += TPB)
+        if (s_tab[e]) atomicAdd(&table[e], s_tab[e]);
+    if (threadIdx.x < n_cls) block_hist[blockIdx.x * n_cls + threadIdx.x] = s_cls[threadIdx.x];
+}
+
+// ---- stable class-major selection of the points of the kept classes + their grouping inputs (PBNet.py:151-170) -------
+// Output position of point i of class c = class_base[c] + #(points j < i of class c): blocks in front come from the
+// per-block histograms, waves in front from a per-wave histogram, lanes in front from ballots.  Deterministic.
+template <typename T>
+__global__ __launch_bounds__(TPB) void k_select_points(const long long* __restrict__ sem_pred, int n, int n_cls,
+                                                      const int* __restrict__ class_base,
+                                                      const int* __restrict__ block_hist, const float* __restrict__ xyz,
+                                                      const T* __restrict__ offset, int ld_off,
+                                                      long long* __restrict__ ins_ind, float* __restrict__ ins_orig,
+                                                      float* __restrict__ ins_off, int* __restrict__ ins_sem) {
+    __shared__ int s_base[SEL_MAX_CLASSES];
+    __shared__ int s_wave[4][SEL_MAX_CLASSES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < n_cls) {
+        int t = class_base[threadIdx.x];
+        if (t >= 0)
+            for (int b = 0; b < (int)blockIdx.x; ++b) t += block_hist[b * n_cls + threadIdx.x];
+        else
+            t = -(1 << 30);                           // dropped class: stays negative whatever is added to it
+        s_base[threadIdx.x] = t;
+    }
+    for (int e = threadIdx.x; e < 4 * SEL_MAX_CLASSES; e += TPB) (&s_wave[0][0])[e] = 0;
+    __syncthreads();
+    const int wbase = blockIdx.x * SEL_BLOCK + wave * (SEL_BLOCK / 4);
+    int cls[SEL_BLOCK / 256];
+#pragma unroll
+    for (int k = 0; k < SEL_BLOCK / 256; ++k) {
+        const int i = wbase + k * 64 + lane;
+        cls[k] = i < n ? (int)sem_pred[i] : -1;
+        if (cls[k] >= 0) atomicAdd(&s_wave[wave][cls[k]], 1);
+    }
+    __syncthreads();
+    // running position per class for this wave (lane c owns class c)
+    int run = 0;
+    if (lane < n_cls) {
+        run = s_base[lane];
+        for (int w = 0; w < wave; ++w) run += s_wave[w][lane];
+    }
+#pragma unroll
+    for (int k = 0; k < SEL_BLOCK / 256; ++k) {
+        const int i = wbase + k * 64 + lane;
+        const int c = cls[k];
+        int pos = -1;
+        unsigned long long todo = __ballot(c >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lc = __shfl(c, leader, 64);
+            const unsigned long long m = __ballot(c == lc);
+            const int start = __shfl(run, lc, 64);
+            if (c == lc) pos = start >= 0 ? start + __popcll(m & ((1ULL << lane) - 1ULL)) : -1;
+            if (lane == lc) run += (run >= 0) ? __popcll(m) : 0;
+            todo &= ~m;
+        }
+        if (pos >= 0) {
+            const float x = xyz[3 * (size_t)i + 0], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+            float ox, oy, oz;
+            const T* o = offset + (size_t)i * ld_off;
+            if constexpr (sizeof(T) == 4) { ox = o[0]; oy = o[1]; oz = o[2]; }
+            else if constexpr (__is_same(T, __hip_bfloat16)) { ox = __bfloat162float(o[0]); oy = __bfloat162float(o[1]); oz = __bfloat162float(o[2]); }
+            else { ox = __half2float(o[0]); oy = __half2float(o[1]); oz = __half2float(o[2]); }
+            ins_ind[pos] = i;
+            ins_orig[3 * (size_t)pos + 0] = x; ins_orig[3 * (size_t)pos + 1] = y; ins_orig[3 * (size_t)pos + 2] = z;
+            ins_off[3 * (size_t)pos + 0] = x + ox; ins_off[3 * (size_t)pos + 1] = y + oy; ins_off[3 * (size_t)pos + 2] = z + oz;
+            ins_sem[pos] = c;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace pbn
 
@@ -99,7 +287,7 @@ extern "C" int pbn_local_scene_rows(const int32_t* ent_row_start, const int32_t*
     if (n_ent < 0 || n_rows < 0 || channels < 0 || ld_out < channels + 2 || ld_feat < channels) return PBN_ERR_ARG;
     if (n_rows == 0) return PBN_OK;
     if (n_ent == 0 || !ent_row_start || !ent_member_start || !ent_scene || !ent_weight || !member_idx || !ins_ind || !xyz ||
-        !point_feat || !sem_score || !sem_pred || !point_idx || !row_scene || !coords || !feat_out)
+        !point_feat || !sem_score || !point_idx || !row_scene || !coords || !feat_out)
         return PBN_ERR_ARG;
     const int esz = dtype == PBN_F32 ? 4 : 2;
     if ((ld_out * esz) % 4 || ((uintptr_t)feat_out & 3) || ((uintptr_t)coords & 15)) return PBN_ERR_ARG;
@@ -128,6 +316,85 @@ extern "C" int pbn_gather_pad_rows(const void* in, int ld_in_bytes, int row_byte
     const long long total = (long long)n * (ld_out_bytes / 4);
     hipLaunchKernelGGL(k_gather_pad_rows, dim3(cdiv(total, TPB)), dim3(TPB), 0, stream, (const unsigned*)in, ld_in_bytes / 4,
                        row_bytes / 4, (const long long*)idx, n, (unsigned*)out, ld_out_bytes / 4);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_mlp_rows(const void* in, int ld_in, int channels, const int64_t* idx_a, const int64_t* idx_b, int n,
+                            const float* w1, const float* scale, const float* shift, const float* slope, int hidden,
+                            const float* w2, const float* b2, int n_out, int sigmoid, void* out, int ld_out, int dtype,
+                            pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || n_out < 1 || ld_out < n_out || ld_in < channels) return PBN_ERR_ARG;
+    if (channels != 32 || (hidden != 16 && hidden != 32)) return PBN_ERR_UNSUPPORTED;
+    if (n == 0) return PBN_OK;
+    if (!in || !w1 || !scale || !shift || !slope || !w2 || !out) return PBN_ERR_ARG;
+    const int esz = dtype == PBN_F32 ? 4 : 2;
+    if ((ld_in * esz) % 16 || ((uintptr_t)in & 15)) return PBN_ERR_ARG;
+    const dim3 grid(cdiv(n, TPB));
+#define PBN_MLP(TT, HH)                                                                                                 \
+    hipLaunchKernelGGL((k_mlp_rows<TT, 32, HH>), grid, dim3(TPB), 0, stream, (const TT*)in, ld_in,                        \
+                       (const long long*)idx_a, (const long long*)idx_b, n, w1, scale, shift, slope, w2, b2, n_out,      \
+                       sigmoid, (TT*)out, ld_out)
+    if (dtype == PBN_F32) { if (hidden == 16) PBN_MLP(float, 16); else PBN_MLP(float, 32); }
+    else if (dtype == PBN_BF16) { if (hidden == 16) PBN_MLP(__hip_bfloat16, 16); else PBN_MLP(__hip_bfloat16, 32); }
+    else if (dtype == PBN_F16) { if (hidden == 16) PBN_MLP(__half, 16); else PBN_MLP(__half, 32); }
+    else return PBN_ERR_ARG;
+#undef PBN_MLP
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_select_blocks(int n) { return n > 0 ? cdiv(n, SEL_BLOCK) : 0; }
+
+extern "C" int pbn_sem_argmax_table(const void* score, int ld, int n_cls, const int32_t* batch, int nb, int n, int dtype,
+                                    int64_t* sem_pred, void* sem_prob, int32_t* table, int32_t* block_hist,
+                                    pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || n_cls < 1 || n_cls > SEL_MAX_CLASSES || nb < 1 || nb > 8 || ld < n_cls || !table) return PBN_ERR_ARG;
+    PBN_HIP_CHECK(hipMemsetAsync(table, 0, sizeof(int) * (size_t)n_cls * nb, stream));
+    if (n == 0) return PBN_OK;
+    if (!score || !sem_pred || !block_hist) return PBN_ERR_ARG;
+    const dim3 grid(cdiv(n, SEL_BLOCK));
+    if (dtype == PBN_F32)
+        hipLaunchKernelGGL(k_sem_argmax_table<float>, grid, dim3(TPB), 0, stream, (const float*)score, ld, n_cls, batch, nb,
+                           n, (long long*)sem_pred, (float*)sem_prob, table, block_hist);
+    else if (dtype == PBN_BF16)
+        hipLaunchKernelGGL(k_sem_argmax_table<__hip_bfloat16>, grid, dim3(TPB), 0, stream, (const __hip_bfloat16*)score, ld,
+                           n_cls, batch, nb, n, (long long*)sem_pred, (__hip_bfloat16*)sem_prob, table, block_hist);
+    else if (dtype == PBN_F16)
+        hipLaunchKernelGGL(k_sem_argmax_table<__half>, grid, dim3(TPB), 0, stream, (const __half*)score, ld, n_cls, batch,
+                           nb, n, (long long*)sem_pred, (__half*)sem_prob, table, block_hist);
+    else
+        return PBN_ERR_ARG;
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_select_points(const int64_t* sem_pred, int n, int n_cls, const int32_t* class_base,
+                                 const int32_t* block_hist, const float* xyz, const void* offset, int ld_off, int dtype,
+                                 int64_t* ins_ind, float* ins_orig, float* ins_off, int32_t* ins_sem,
+                                 pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || n_cls < 1 || n_cls > SEL_MAX_CLASSES || ld_off < 3) return PBN_ERR_ARG;
+    if (n == 0) return PBN_OK;
+    if (!sem_pred || !class_base || !block_hist || !xyz || !offset || !ins_ind || !ins_orig || !ins_off || !ins_sem)
+        return PBN_ERR_ARG;
+    const dim3 grid(cdiv(n, SEL_BLOCK));
+    if (dtype == PBN_F32)
+        hipLaunchKernelGGL(k_select_points<float>, grid, dim3(TPB), 0, stream, (const long long*)sem_pred, n, n_cls,
+                           class_base, block_hist, xyz, (const float*)offset, ld_off, (long long*)ins_ind, ins_orig, ins_off,
+                           ins_sem);
+    else if (dtype == PBN_BF16)
+        hipLaunchKernelGGL(k_select_points<__hip_bfloat16>, grid, dim3(TPB), 0, stream, (const long long*)sem_pred, n, n_cls,
+                           class_base, block_hist, xyz, (const __hip_bfloat16*)offset, ld_off, (long long*)ins_ind, ins_orig,
+                           ins_off, ins_sem);
+    else if (dtype == PBN_F16)
+        hipLaunchKernelGGL(k_select_points<__half>, grid, dim3(TPB), 0, stream, (const long long*)sem_pred, n, n_cls,
+                           class_base, block_hist, xyz, (const __half*)offset, ld_off, (long long*)ins_ind, ins_orig, ins_off,
+                           ins_sem);
+    else
+        return PBN_ERR_ARG;
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }

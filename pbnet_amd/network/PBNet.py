@@ -78,12 +78,18 @@ class PBNet(nn.Module):
         """teacher: optional dict(sem_score [N,sem_num], offset [N,3]) that REPLACES the two head outputs after they
         have been computed -- a bench/test hook: randomly initialised heads cannot produce instances."""
         dev = torch.device("cuda", torch.cuda.current_device())
-        stage1 = self.backbone_stage(feat_voxel.to(dev), xyz_voxel.to(dev), v2p_v1.to(dev))
+        fused = not torch.is_grad_enabled()           # inference: the stage glue runs as fused launches (stage_ops)
+        stage1 = self.backbone_stage(feat_voxel.to(dev), xyz_voxel.to(dev), v2p_v1.to(dev), fused)
         if teacher is not None:
             stage1["sem_pred_score_p"] = teacher["sem_score"].to(dev, stage1["sem_pred_score_p"].dtype)
-            stage1["sem_pred_score_sfp"] = torch.softmax(stage1["sem_pred_score_p"].float(), 1).to(stage1["point_feat_p"].dtype)
             stage1["offset_pred_p"] = teacher["offset"].to(dev, stage1["offset_pred_p"].dtype)
-            stage1["sem_pred_p"] = stage1["sem_pred_score_p"].max(1)[1]
+            if not fused:
+                stage1["sem_pred_score_sfp"] = torch.softmax(stage1["sem_pred_score_p"].float(), 1).to(stage1["point_feat_p"].dtype)
+                stage1["sem_pred_p"] = stage1["sem_pred_score_p"].max(1)[1]
+        if fused:
+            nb = self.batch_size if task == "train" else 3                          # PBNet.py:167-170
+            stage1["sem_pred_p"], stage1["sem_prob_p"], stage1["table"], stage1["block_hist"] = \
+                stage_ops.sem_argmax_table(stage1["sem_pred_score_p"], stage1["batch_head_p"], nb)
         ret = {"sem_pred_p": stage1["sem_pred_p"], "sem_pred_score_p": stage1["sem_pred_score_p"],
                "offset_pred_p": stage1["offset_pred_p"]}
         if epoch > self.cluster_epoch:
@@ -92,16 +98,28 @@ class PBNet(nn.Module):
         return ret
 
     # ---- PBNet.py:117-136 -------------------------------------------------------------------------------------
-    def backbone_stage(self, feat_voxel, xyz_voxel, v2p_v1):
+    def backbone_stage(self, feat_voxel, xyz_voxel, v2p_v1, fused=False):
         with section("a3_coords"):
             inputs_v1 = ME.SparseTensor(feat_voxel, xyz_voxel)
         with section("a4_unet"):
             point_feat = self.MEUnet(inputs_v1)
         _sec = section("a5_heads_gather"); _sec.__enter__()
+        v2p = v2p_v1.long()
+        if fused:
+            # heads evaluated straight at the points (one launch each): the same rows, so the same numbers, as
+            # evaluating them at the voxels and gathering (PBNet.py:124-134)
+            f = point_feat.F
+            out = {
+                "point_feat_p": f[v2p],
+                "sem_pred_score_p": stage_ops.mlp_rows(self.linear_sem, f, v2p),
+                "offset_pred_p": stage_ops.mlp_rows(self.linear_offset, f, v2p),
+                "batch_head_p": xyz_voxel[:, 0].to(torch.int32)[v2p],
+            }
+            _sec.__exit__(None, None, None)
+            return out
         sem_pred_score = self.linear_sem(point_feat)
         sem_pred_score_sf = self.soft_max(sem_pred_score)
         offsets_pred = self.linear_offset(point_feat)
-        v2p = v2p_v1.long()
         out = {
             "point_feat_p": point_feat.F[v2p],
             "sem_pred_score_p": sem_pred_score.F[v2p],
@@ -117,30 +135,46 @@ class PBNet(nn.Module):
     def cluster_stage(self, s1, xyz_original, ins_label, task):
         dev = xyz_original.device
         xyz_original = xyz_original.float()
-        sem_pred_p, batch_head_p = s1["sem_pred_p"], s1["batch_head_p"].long()
-        point_feat_p, sem_sfp, offset_pred_p = s1["point_feat_p"], s1["sem_pred_score_sfp"], s1["offset_pred_p"]
+        fused = "table" in s1
+        sem_pred_p = s1["sem_pred_p"]
+        point_feat_p, offset_pred_p = s1["point_feat_p"], s1["offset_pred_p"]
+        sem_sfp = s1["sem_prob_p"].view(-1, 1) if fused else s1["sem_pred_score_sfp"]
         self.cluster_batch = self.batch_size if task == "train" else 3          # PBNet.py:167-170
         nb = self.cluster_batch
         n_cls = int(self.sem_num)
 
         # (a6) per-class selection, all classes at once; host learns the [class, batch] population table
         _sec = section("a6_select"); _sec.__enter__()
-        table = torch.bincount(sem_pred_p * nb + batch_head_p, minlength=n_cls * nb)[:n_cls * nb].view(n_cls, nb)
+        if fused:
+            table = s1["table"]
+        else:
+            batch_head_p = s1["batch_head_p"].long()
+            table = torch.bincount(sem_pred_p * nb + batch_head_p, minlength=n_cls * nb)[:n_cls * nb].view(n_cls, nb)
         table_h = table.cpu()                                                     # sync 1
         assert int(table_h.sum()) == sem_pred_p.shape[0], "batch index outside [0, cluster_batch)"  # PBNet.py:286
         per_class = table_h.sum(1)
         classes = [c for c in range(2, n_cls) if not (float(per_class[c]) < float(self.count_mean[c] * 0.05))]
         if not classes:
             return self._empty_stage(dev, task)
-        keep = torch.zeros(n_cls, dtype=torch.bool)
-        keep[classes] = True
-        key = torch.where(keep.to(dev)[sem_pred_p], sem_pred_p, torch.full_like(sem_pred_p, n_cls))
-        order = torch.sort(key, stable=True)[1]
         m = int(per_class[classes].sum())
-        ins_ind = order[:m]                                   # class-major, ascending point index inside a class
-        ins_orig = xyz_original[ins_ind]
-        ins_offseted = ins_orig + offset_pred_p[ins_ind].float()                 # PBNet.py:165 (fp32 add)
-        ins_sem = sem_pred_p[ins_ind].to(torch.int32)
+        if fused:
+            # stable class-major selection + the grouping inputs in one launch (positions from the class totals)
+            class_base = torch.full((n_cls,), -1, dtype=torch.int32)
+            run = 0
+            for c in classes:
+                class_base[c] = run
+                run += int(per_class[c])
+            ins_ind, ins_orig, ins_offseted, ins_sem = stage_ops.select_points(
+                sem_pred_p, class_base.to(dev), s1["block_hist"], xyz_original, offset_pred_p, m)
+        else:
+            keep = torch.zeros(n_cls, dtype=torch.bool)
+            keep[classes] = True
+            key = torch.where(keep.to(dev)[sem_pred_p], sem_pred_p, torch.full_like(sem_pred_p, n_cls))
+            order = torch.sort(key, stable=True)[1]
+            ins_ind = order[:m]                                   # class-major, ascending point index inside a class
+            ins_orig = xyz_original[ins_ind]
+            ins_offseted = ins_orig + offset_pred_p[ins_ind].float()                 # PBNet.py:165 (fp32 add)
+            ins_sem = sem_pred_p[ins_ind].to(torch.int32)
         seg_len = table[classes].reshape(-1).to(torch.int32)                      # segments = (class, batch) in order
         _sec.__exit__(None, None, None)
 
@@ -212,7 +246,7 @@ class PBNet(nn.Module):
                                 torch.tensor(ent_weight, dtype=torch.float32).view(torch.int32)]).to(dev)
             point_idx, row_scene, coords, feat = stage_ops.local_scene_rows(
                 packed, n_ent, n_rows, res.member_idx, ins_ind, xyz_original, LOCAL_VOXEL, point_feat_p, sem_sfp,
-                sem_pred_p)
+                None if fused else sem_pred_p)
         else:
             ent_scene = torch.repeat_interleave(torch.arange(len(scene_len)), torch.tensor(scene_len))
             d = lambda t: t.to(dev)

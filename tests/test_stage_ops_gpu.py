@@ -77,3 +77,74 @@ def test_gather_pad_rows():
                                      ctypes.c_void_p(out.data_ptr()), 80, N.current_stream())
     assert rc == 0
     assert torch.equal(out[:, :34], x[idx]) and (out[:, 34:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("n_out,sigmoid,hidden", [(20, False, 16), (3, False, 16), (1, True, 16), (32, False, 32)])
+def test_mlp_rows_matches_modules(dtype, tol, n_out, sigmoid, hidden):
+    """PBNet.py:43-82 heads: Linear -> BatchNorm(eval) -> PReLU -> Linear [-> Sigmoid], with a two-level row index."""
+    import pbnet_amd.MinkowskiEngine as ME
+    torch.manual_seed(n_out)
+    layers = [ME.MinkowskiLinear(32, hidden, bias=False), ME.MinkowskiBatchNorm(hidden), ME.MinkowskiPReLU(),
+              ME.MinkowskiLinear(hidden, n_out, bias=True)]
+    if sigmoid:
+        layers.append(ME.MinkowskiSigmoid())
+    head = torch.nn.Sequential(*layers).eval()
+    with torch.no_grad():
+        head[1].bn.running_mean.normal_(0, 0.3)
+        head[1].bn.running_var.uniform_(0.5, 2.0)
+        head[1].bn.weight.uniform_(0.5, 1.5)
+        head[1].bn.bias.normal_(0, 0.2)
+        head[2].module.weight.fill_(0.2)
+    x = torch.randn(3000, 32)
+    idx_a = torch.randint(0, 2500, (4000,))
+    idx_b = torch.randperm(3000)[:2500]
+    with torch.no_grad():
+        h = head[0].linear(x)
+        h = head[2].module(head[1].bn(h))
+        want = head[3].linear(h)
+        if sigmoid:
+            want = torch.sigmoid(want)
+        want = want[idx_b[idx_a]]
+    head = head.to(DEV)
+    got = stage_ops.mlp_rows(head, x.to(DEV).to(dtype), idx_a.to(DEV), idx_b.to(DEV))
+    assert got.shape == (4000, n_out) and got.dtype == dtype
+    assert (got.float().cpu() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sem_argmax_table_and_select_points(dtype):
+    """PBNet.py:134,151-170: arg-max / own-class softmax / population table, then the stable class-major selection."""
+    torch.manual_seed(4)
+    n, s, nb = 70001, 20, 3
+    score = (torch.randn(n, s) * 3).to(dtype).to(DEV)
+    score[:5000, 7] += 20                                           # long single-class runs
+    batch = torch.randint(0, nb, (n,), dtype=torch.int32, device=DEV)
+    sem_pred, sem_prob, table, block_hist = stage_ops.sem_argmax_table(score, batch, nb)
+    sf = score.float()
+    want_pred = sf.max(1)[1]
+    assert torch.equal(sem_pred, want_pred)
+    want_prob = torch.softmax(sf, 1).gather(1, want_pred.view(-1, 1)).view(-1)
+    assert (sem_prob.float() - want_prob).abs().max().item() <= (1e-6 if dtype == torch.float32 else 4e-3)
+    want_table = torch.bincount(want_pred * nb + batch.long(), minlength=s * nb).view(s, nb)
+    assert torch.equal(table.long(), want_table)
+    assert torch.equal(block_hist.sum(0).long(), want_table.sum(1))
+    # selection: drop classes 0, 1 and two more
+    per_class = want_table.sum(1).cpu()
+    classes = [c for c in range(2, s) if c not in (5, 11)]
+    class_base = torch.full((s,), -1, dtype=torch.int32)
+    run = 0
+    for c in classes:
+        class_base[c] = run
+        run += int(per_class[c])
+    xyz = torch.randn(n, 3, device=DEV)
+    offset = torch.randn(n, 3, device=DEV).to(dtype)
+    ins_ind, ins_orig, ins_off, ins_sem = stage_ops.select_points(sem_pred, class_base.to(DEV), block_hist, xyz, offset, run)
+    keep = torch.zeros(s, dtype=torch.bool)
+    keep[classes] = True
+    key = torch.where(keep.to(DEV)[want_pred], want_pred, torch.full_like(want_pred, s))
+    order = torch.sort(key, stable=True)[1][:run]
+    assert torch.equal(ins_ind, order)
+    assert torch.equal(ins_orig, xyz[order])
+    assert torch.equal(ins_off, xyz[order] + offset[order].float())
+    assert torch.equal(ins_sem, want_pred[order].to(torch.int32))
