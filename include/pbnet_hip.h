@@ -223,6 +223,20 @@ int pbn_select_points(const int64_t* sem_pred, int n, int n_cls, const int32_t* 
                       const float* xyz, const void* offset, int ld_off, int dtype, int64_t* ins_ind, float* ins_orig,
                       float* ins_off, int32_t* ins_sem, pbn_stream_t stream);
 
+/* get_proposal (network/PBNet.py:317-347) and the score-branch inputs (:240-252) as an order-preserving compaction:
+ *   pbn_mask_count    : rows with mask_score > thd per local scene (per_scene, zeroed here) and per block of rows
+ *                       (block_cnt int32[pbn_select_blocks(n)]); the host turns per_scene into the dense renumbering
+ *                       of the surviving scenes ("remove null proposals", :342-345) and the proposal offsets;
+ *   pbn_proposal_rows : for every kept row, in row order: proposals_idx = (dense_of[row_scene], point_idx),
+ *                       proposals_ms = its mask score and, optionally, the score-branch voxel coordinate
+ *                       (dense id, floor(xyz[p] * scale * inv_voxel)) and input feature row point_feat[p, 0:channels]. */
+int pbn_mask_count(const void* mask_score, int ld, float thd, const int64_t* row_scene, int n, int n_scenes, int dtype,
+                   int32_t* per_scene, int32_t* block_cnt, pbn_stream_t stream);
+int pbn_proposal_rows(const void* mask_score, int ld, float thd, const int64_t* row_scene, const int64_t* point_idx, int n,
+                      const int32_t* dense_of, const int32_t* block_cnt, const float* xyz, float scale, float inv_voxel,
+                      const void* point_feat, int ld_feat, int channels, int dtype, int64_t* proposals_idx,
+                      void* proposals_ms, int32_t* coords, void* feat_out, pbn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * One-call sub-pipelines (csrc/executor.hip): they only sequence the entry points above.
  *

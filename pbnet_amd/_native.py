@@ -76,6 +76,9 @@ SIGNATURES = {
     "pbn_sem_argmax_table": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_int, c_int, c_vp, c_vp, c_i32p, c_i32p, c_vp]),
     "pbn_select_points": (c_int, [c_vp, c_int, c_int, c_i32p, c_i32p, c_f32p, c_vp, c_int, c_int, c_vp, c_f32p, c_f32p,
                                   c_i32p, c_vp]),
+    "pbn_mask_count": (c_int, [c_vp, c_int, c_float, c_vp, c_int, c_int, c_int, c_i32p, c_i32p, c_vp]),
+    "pbn_proposal_rows": (c_int, [c_vp, c_int, c_float, c_vp, c_vp, c_int, c_i32p, c_i32p, c_f32p, c_float, c_float, c_vp,
+                                  c_int, c_int, c_int, c_vp, c_vp, c_i32p, c_vp, c_vp]),
     "pbn_kernel_map_cube": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_coords_arena_bytes": (c_size, [c_int, c_int, ctypes.POINTER(CoordsLayout)]),
     "pbn_coords_build": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(CoordsLayout), c_vp]),

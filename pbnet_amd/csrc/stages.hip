@@ -272,6 +272,109 @@ __global__ __launch_bounds__(TPB) void k_select_points(const long long* __restri
     }
 }
 
+
+// ---- proposals (PBNet.py:317-347 + 240-252): rows whose mask score passes the threshold, order preserved ------------
+template <typename T> __device__ __forceinline__ float ld_f32(const T* p);
+template <> __device__ __forceinline__ float ld_f32<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld_f32<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <> __device__ __forceinline__ float ld_f32<__half>(const __half* p) { return __half2float(*p); }
+
+// pass 1: kept rows per block of SEL_BLOCK rows and per local scene (wave-aggregated atomics: rows are grouped by scene)
+template <typename T>
+__global__ __launch_bounds__(TPB) void k_mask_count(const T* __restrict__ score, int ld, float thd,
+                                                   const long long* __restrict__ row_scene, int n, int n_scenes,
+                                                   int* __restrict__ per_scene, int* __restrict__ block_cnt) {
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int base = blockIdx.x * SEL_BLOCK;
+    int mine = 0;
+    for (int k = 0; k < SEL_BLOCK / TPB; ++k) {
+        const int i = base + k * TPB + threadIdx.x;
+        const bool keep = i < n && ld_f32<T>(score + (size_t)i * ld) > thd;
+        const int sc = keep ? (int)row_scene[i] : -1;
+        unsigned long long todo = __ballot(keep);
+        mine += keep ? 1 : 0;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int ls = __shfl(sc, leader, 64);
+            const unsigned long long m = __ballot(sc == ls);
+            if (lane == leader && ls >= 0 && ls < n_scenes) atomicAdd(&per_scene[ls], __popcll(m));
+            todo &= ~m;
+        }
+    }
+    mine = wave_reduce_add(mine);
+    if (lane == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_cnt;
+}
+
+// pass 2: compaction.  Thread t of a block owns SEL_BLOCK/TPB CONSECUTIVE rows, so positions follow the row order.
+template <typename T>
+__global__ __launch_bounds__(TPB) void k_proposal_rows(const T* __restrict__ score, int ld, float thd,
+                                                      const long long* __restrict__ row_scene,
+                                                      const long long* __restrict__ point_idx, int n,
+                                                      const int* __restrict__ dense_of, const int* __restrict__ block_cnt,
+                                                      const float* __restrict__ xyz, float scale, float inv_voxel,
+                                                      const uint4* __restrict__ point_feat, int ld_feat_vec, int vpr,
+                                                      long long* __restrict__ prop_idx, T* __restrict__ prop_ms,
+                                                      int* __restrict__ coords, uint4* __restrict__ feat) {
+    constexpr int PER = SEL_BLOCK / TPB;
+    __shared__ int wtot[TPB / 64];
+    __shared__ int s_base;
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += TPB) part += block_cnt[b];
+    part = wave_reduce_add(part);
+    if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+    const int block_base = s_base;
+    const int r0 = blockIdx.x * SEL_BLOCK + threadIdx.x * PER;
+    bool keep[PER];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = r0 + k;
+        keep[k] = i < n && ld_f32<T>(score + (size_t)i * ld) > thd;
+        cnt += keep[k] ? 1 : 0;
+    }
+    // exclusive prefix of cnt over the block
+    int incl = cnt;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wtot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wtot[w];
+    int pos = block_base + woff + incl - cnt;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (!keep[k]) continue;
+        const int i = r0 + k;
+        const long long p = point_idx[i];
+        const int dense = dense_of[(int)row_scene[i]];
+        prop_idx[2 * (size_t)pos + 0] = dense;
+        prop_idx[2 * (size_t)pos + 1] = p;
+        prop_ms[pos] = score[(size_t)i * ld];
+        if (coords) {
+            // (xyz * scale) / voxel with device-tensor-by-host-scalar semantics: two fp32 multiplications
+            const float x = (xyz[3 * p + 0] * scale) * inv_voxel, y = (xyz[3 * p + 1] * scale) * inv_voxel,
+                        z = (xyz[3 * p + 2] * scale) * inv_voxel;
+            reinterpret_cast<int4*>(coords)[pos] = make_int4(dense, (int)floorf(x), (int)floorf(y), (int)floorf(z));
+        }
+        if (feat)
+            for (int v = 0; v < vpr; ++v) feat[(size_t)pos * vpr + v] = point_feat[(size_t)p * ld_feat_vec + v];
+        ++pos;
+    }
+}
+
 }  // namespace
 }  // namespace pbn
 
@@ -395,6 +498,66 @@ extern "C" int pbn_select_points(const int64_t* sem_pred, int n, int n_cls, cons
                            ins_sem);
     else
         return PBN_ERR_ARG;
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_mask_count(const void* mask_score, int ld, float thd, const int64_t* row_scene, int n, int n_scenes,
+                              int dtype, int32_t* per_scene, int32_t* block_cnt, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || n_scenes < 0 || ld < 1) return PBN_ERR_ARG;
+    if (n_scenes > 0) {
+        if (!per_scene) return PBN_ERR_ARG;
+        PBN_HIP_CHECK(hipMemsetAsync(per_scene, 0, sizeof(int) * (size_t)n_scenes, stream));
+    }
+    if (n == 0) return PBN_OK;
+    if (!mask_score || !row_scene || !block_cnt) return PBN_ERR_ARG;
+    const dim3 grid(cdiv(n, SEL_BLOCK));
+    if (dtype == PBN_F32)
+        hipLaunchKernelGGL(k_mask_count<float>, grid, dim3(TPB), 0, stream, (const float*)mask_score, ld, thd,
+                           (const long long*)row_scene, n, n_scenes, per_scene, block_cnt);
+    else if (dtype == PBN_BF16)
+        hipLaunchKernelGGL(k_mask_count<__hip_bfloat16>, grid, dim3(TPB), 0, stream, (const __hip_bfloat16*)mask_score, ld,
+                           thd, (const long long*)row_scene, n, n_scenes, per_scene, block_cnt);
+    else if (dtype == PBN_F16)
+        hipLaunchKernelGGL(k_mask_count<__half>, grid, dim3(TPB), 0, stream, (const __half*)mask_score, ld, thd,
+                           (const long long*)row_scene, n, n_scenes, per_scene, block_cnt);
+    else
+        return PBN_ERR_ARG;
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_proposal_rows(const void* mask_score, int ld, float thd, const int64_t* row_scene,
+                                 const int64_t* point_idx, int n, const int32_t* dense_of, const int32_t* block_cnt,
+                                 const float* xyz, float scale, float inv_voxel, const void* point_feat, int ld_feat,
+                                 int channels, int dtype, int64_t* proposals_idx, void* proposals_ms, int32_t* coords,
+                                 void* feat_out, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || ld < 1) return PBN_ERR_ARG;
+    if (n == 0) return PBN_OK;
+    if (!mask_score || !row_scene || !point_idx || !dense_of || !block_cnt || !proposals_idx || !proposals_ms)
+        return PBN_ERR_ARG;
+    const int esz = dtype == PBN_F32 ? 4 : 2;
+    int vpr = 0;
+    if (feat_out) {
+        if (!point_feat || channels < 1 || (channels * esz) % 16 || (ld_feat * esz) % 16 ||
+            (((uintptr_t)point_feat | (uintptr_t)feat_out) & 15))
+            return PBN_ERR_ARG;
+        vpr = channels * esz / 16;
+    }
+    if (coords && (!xyz || ((uintptr_t)coords & 15))) return PBN_ERR_ARG;
+    const dim3 grid(cdiv(n, SEL_BLOCK));
+#define PBN_PR(TT)                                                                                                      \
+    hipLaunchKernelGGL(k_proposal_rows<TT>, grid, dim3(TPB), 0, stream, (const TT*)mask_score, ld, thd,                    \
+                       (const long long*)row_scene, (const long long*)point_idx, n, dense_of, block_cnt, xyz, scale,     \
+                       inv_voxel, (const uint4*)point_feat, feat_out ? ld_feat * esz / 16 : 0, vpr,                      \
+                       (long long*)proposals_idx, (TT*)proposals_ms, coords, (uint4*)feat_out)
+    if (dtype == PBN_F32) PBN_PR(float);
+    else if (dtype == PBN_BF16) PBN_PR(__hip_bfloat16);
+    else if (dtype == PBN_F16) PBN_PR(__half);
+    else return PBN_ERR_ARG;
+#undef PBN_PR
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }

@@ -136,6 +136,7 @@ class PBNet(nn.Module):
         dev = xyz_original.device
         xyz_original = xyz_original.float()
         fused = "table" in s1
+        fused_glue = not torch.is_grad_enabled()      # inference: stage glue as fused launches (stage_ops)
         sem_pred_p = s1["sem_pred_p"]
         point_feat_p, offset_pred_p = s1["point_feat_p"], s1["offset_pred_p"]
         sem_sfp = s1["sem_prob_p"].view(-1, 1) if fused else s1["sem_pred_score_sfp"]
@@ -270,36 +271,54 @@ class PBNet(nn.Module):
         with section("a18_mask_coords"):
             inputs_v2 = ME.SparseTensor(feat, coords)
         with section("a18_mask_unet"):
-            mask_score = self.linear_binary(self.D_Unet(inputs_v2)).F[inputs_v2.inverse_mapping]   # [R, 1]
+            if fused_glue:   # head evaluated at the rows (PBNet.py:247): same numbers as head-then-gather, one launch
+                mask_score = stage_ops.mlp_rows(self.linear_binary, self.D_Unet(inputs_v2).F, inputs_v2.inverse_mapping)
+            else:
+                mask_score = self.linear_binary(self.D_Unet(inputs_v2)).F[inputs_v2.inverse_mapping]   # [R, 1]
         if task != "test":
             gt_rows = torch.tensor(scene_gt, dtype=torch.long).to(dev)[row_scene]
             lab = ins_label[point_idx]
             gt_mask = (lab == gt_rows).long()
             gt_mask[lab == -100] = -1
             out["mask_scores"] = (mask_score, gt_mask.detach())
+        coords3 = feat3 = None
         with section("a19_proposals"):
-            out["proposals"] = self.get_proposal(row_scene, point_idx, mask_score, n_scenes=len(scene_len))
+            if fused_glue:
+                out["proposals"], coords3, feat3 = self._proposals_fused(row_scene, point_idx, mask_score, len(scene_len),
+                                                                         xyz_original, point_feat_p)
+            else:
+                out["proposals"] = self.get_proposal(row_scene, point_idx, mask_score, n_scenes=len(scene_len))
 
         # (a20) score branch
         proposals_idx, proposals_offset, _, _ = out["proposals"]
         if proposals_offset.shape[0] > 1:
-            pidx = proposals_idx[:, 1]
-            c3 = torch.floor(xyz_original[pidx] * self.scale_size / self.voxel_size).to(torch.int32)
-            coords3 = torch.cat([proposals_idx[:, 0:1].to(torch.int32), c3], 1)
+            if coords3 is None:
+                pidx = proposals_idx[:, 1]
+                c3 = torch.floor(xyz_original[pidx] * self.scale_size / self.voxel_size).to(torch.int32)
+                coords3 = torch.cat([proposals_idx[:, 0:1].to(torch.int32), c3], 1)
+                feat3 = point_feat_p[pidx]
             with section("a20_score_coords"):
-                inputs_v3 = ME.SparseTensor(point_feat_p[pidx], coords3)
+                inputs_v3 = ME.SparseTensor(feat3, coords3)
             with section("a20_score_unet"):
-                iou_feat = self.linear_IOU_feat(self.score_Unet(inputs_v3))
+                if fused_glue:
+                    iou_feat_f = stage_ops.mlp_rows(self.linear_IOU_feat, self.score_Unet(inputs_v3).F)
+                else:
+                    iou_feat = self.linear_IOU_feat(self.score_Unet(inputs_v3))
             with section("a20_pool_head"):
                 # global max + avg pooling per proposal (PBNet.py:274-276); rows are grouped by proposal id
                 if torch.is_grad_enabled():      # training: differentiable torch reductions
                     global_feat = self.global_max_pool(iou_feat) + self.global_avg_pool(iou_feat)
+                    out["clt_scores"] = self.linear_IOU(global_feat).F.view(-1)
                 else:                            # inference: one deterministic segment-pool kernel
                     from ..MinkowskiEngine.nn import segment_pool, _PooledTensor
                     n_prop = int(proposals_offset.shape[0]) - 1
-                    mx, av = segment_pool(iou_feat.F, inputs_v3.C[:, 0], n_prop)
-                    global_feat = _PooledTensor((mx + av).to(iou_feat.F.dtype))
-                out["clt_scores"] = self.linear_IOU(global_feat).F.view(-1)
+                    f = iou_feat_f if fused_glue else iou_feat.F
+                    mx, av = segment_pool(f, inputs_v3.C[:, 0], n_prop)
+                    pooled = (mx + av).to(f.dtype)
+                    if fused_glue:
+                        out["clt_scores"] = stage_ops.mlp_rows(self.linear_IOU, pooled).view(-1)
+                    else:
+                        out["clt_scores"] = self.linear_IOU(_PooledTensor(pooled)).F.view(-1)
         else:
             out["clt_scores"] = torch.zeros(0, dtype=torch.float32, device=dev)
         return out
@@ -312,6 +331,24 @@ class PBNet(nn.Module):
         if task != "test":
             out["mask_scores"] = (torch.zeros(0, 1, device=dev), z)
         return out
+
+    def _proposals_fused(self, row_scene, point_idx, mask_score, n_scenes, xyz_original, point_feat_p,
+                         mask_score_thd=MASK_THD):
+        """get_proposal (PBNet.py:317-347) plus the score-branch inputs (:240-252) as two launches around ONE host read
+        (kept rows per local scene).  Same outputs as get_proposal; also returns (coords3, feat3)."""
+        dev = row_scene.device
+        per_scene_d, block_cnt = stage_ops.mask_count(mask_score, mask_score_thd, row_scene, n_scenes)
+        per_scene = per_scene_d.cpu().long()                                         # sync
+        total = int(per_scene.sum())
+        alive = per_scene > 0
+        cluster_id_v = torch.nonzero(alive).view(-1)                                # surviving scene ids (host)
+        proposals_offset = torch.zeros(int(alive.sum()) + 1, dtype=torch.int64)
+        proposals_offset[1:] = torch.cumsum(per_scene[alive], 0)
+        dense_of = (torch.cumsum(alive.to(torch.int32), 0) - 1).to(torch.int32)     # PBNet.py:342-345
+        prop_idx, prop_ms, coords3, feat3 = stage_ops.proposal_rows(
+            mask_score, mask_score_thd, row_scene, point_idx, dense_of.to(dev), block_cnt, total, xyz_original,
+            self.scale_size, self.voxel_size, point_feat_p)
+        return (prop_idx, proposals_offset.to(dev), cluster_id_v.to(dev), prop_ms), coords3, feat3
 
     # ---- PBNet.py:317-347 as one device compaction ----------------------------------------------------------------
     def get_proposal(self, row_scene, point_idx, mask_score, mask_score_thd=MASK_THD, n_scenes=None):

@@ -124,3 +124,45 @@ def select_points(sem_pred, class_base, block_hist, xyz, offset, m):
                                    N.ptr(ins_orig), N.ptr(ins_off), N.ptr(ins_sem), N.current_stream())
     N.check(rc, "pbn_select_points")
     return ins_ind, ins_orig, ins_off, ins_sem
+
+
+def mask_count(mask_score, thd, row_scene, n_scenes):
+    """First half of get_proposal (PBNet.py:317-333): kept rows per local scene and per row block (device tensors)."""
+    N.require_cuda(mask_score, row_scene)
+    n = int(row_scene.shape[0])
+    dev = mask_score.device
+    lib = N.lib()
+    ms = mask_score.view(n, -1)
+    assert ms.stride(1) == 1 and row_scene.dtype == torch.int64
+    per_scene = torch.empty(max(n_scenes, 1), dtype=torch.int32, device=dev)
+    block_cnt = torch.empty(max(lib.pbn_select_blocks(n), 1), dtype=torch.int32, device=dev)
+    rc = lib.pbn_mask_count(N.c_vp(ms.data_ptr()), ms.stride(0), float(thd), N.ptr(row_scene), n, int(n_scenes),
+                            _DT[ms.dtype], N.ptr(per_scene), N.ptr(block_cnt), N.current_stream())
+    N.check(rc, "pbn_mask_count")
+    return per_scene[:n_scenes], block_cnt
+
+
+def proposal_rows(mask_score, thd, row_scene, point_idx, dense_of, block_cnt, total, xyz=None, scale=1.0, voxel=1.0,
+                  point_feat=None):
+    """Second half of get_proposal (+ PBNet.py:240-252 when xyz / point_feat are given).  Returns (proposals_idx i64[P,2],
+    proposals_ms [P], coords i32[P,4] or None, feat [P,C] or None)."""
+    n = int(row_scene.shape[0])
+    dev = mask_score.device
+    ms = mask_score.view(n, -1)
+    prop_idx = torch.empty(total, 2, dtype=torch.int64, device=dev)
+    prop_ms = torch.empty(total, dtype=ms.dtype, device=dev)
+    coords = torch.empty(total, 4, dtype=torch.int32, device=dev) if xyz is not None else None
+    feat = None
+    c = ld_feat = 0
+    if point_feat is not None:
+        assert point_feat.stride(1) == 1 and point_feat.dtype == ms.dtype
+        c, ld_feat = int(point_feat.shape[1]), point_feat.stride(0)
+        feat = torch.empty(total, c, dtype=point_feat.dtype, device=dev)
+    vp = N.c_vp
+    rc = N.lib().pbn_proposal_rows(
+        vp(ms.data_ptr()), ms.stride(0), float(thd), N.ptr(row_scene), N.ptr(point_idx), n, N.ptr(dense_of),
+        N.ptr(block_cnt), N.ptr(xyz), float(np.float32(scale)), reciprocal_f32(voxel),
+        None if point_feat is None else vp(point_feat.data_ptr()), ld_feat, c, _DT[ms.dtype], N.ptr(prop_idx),
+        vp(prop_ms.data_ptr()), N.ptr(coords), None if feat is None else vp(feat.data_ptr()), N.current_stream())
+    N.check(rc, "pbn_proposal_rows")
+    return prop_idx, prop_ms, coords, feat

@@ -148,3 +148,39 @@ def test_sem_argmax_table_and_select_points(dtype):
     assert torch.equal(ins_orig, xyz[order])
     assert torch.equal(ins_off, xyz[order] + offset[order].float())
     assert torch.equal(ins_sem, want_pred[order].to(torch.int32))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_proposal_compaction_matches_get_proposal(dtype):
+    """PBNet.py:317-347 (+240-252): threshold, per-scene counts, dense renumbering of surviving scenes, order kept."""
+    torch.manual_seed(8)
+    n_scenes, n_points = 41, 9000
+    lens = torch.randint(0, 900, (n_scenes,))
+    lens[3] = 0
+    lens[17] = 5000
+    row_scene = torch.repeat_interleave(torch.arange(n_scenes), lens).to(DEV)
+    r = int(row_scene.shape[0])
+    point_idx = torch.randint(0, n_points, (r,), device=DEV)
+    score = torch.rand(r, 1, device=DEV).to(dtype)
+    score[row_scene == 9] = 0.1                                     # a scene that dies entirely
+    xyz = (torch.rand(n_points, 3, device=DEV) * 8 - 2)
+    feat = torch.randn(n_points, 32, device=DEV).to(dtype)
+    thd, scale, voxel = 0.45, 1, 0.02
+    per_scene_d, block_cnt = stage_ops.mask_count(score, thd, row_scene, n_scenes)
+    keep = score.view(-1).float() > thd
+    want_per_scene = torch.bincount(row_scene[keep], minlength=n_scenes)
+    assert torch.equal(per_scene_d.long(), want_per_scene)
+    per_scene = want_per_scene.cpu()
+    alive = per_scene > 0
+    dense_of = (torch.cumsum(alive.to(torch.int32), 0) - 1).to(torch.int32)
+    total = int(per_scene.sum())
+    pidx, pms, coords, f3 = stage_ops.proposal_rows(score, thd, row_scene, point_idx, dense_of.to(DEV), block_cnt, total,
+                                                    xyz, scale, voxel, feat)
+    valid = torch.nonzero(keep).view(-1)
+    want_idx = torch.stack([dense_of.to(DEV).long()[row_scene[valid]], point_idx[valid]], 1)
+    assert torch.equal(pidx, want_idx)
+    assert torch.equal(pms, score[valid].view(-1))
+    p = want_idx[:, 1]
+    want_c = torch.cat([want_idx[:, 0:1].to(torch.int32), torch.floor(xyz[p] * scale / voxel).to(torch.int32)], 1)
+    assert torch.equal(coords, want_c)
+    assert torch.equal(f3, feat[p])
