@@ -24,6 +24,7 @@
 // parity configuration (1e-4 vs the oracle); bf16/f16 slabs use v_mfma_f32_16x16x32_{bf16,f16}.
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
+#include <cmath>
 #include <cstdlib>
 #include "pbn_common.h"
 
@@ -497,11 +498,18 @@ int launch_ring(ConvArgs a, int ngroups, float* workspace, size_t workspace_byte
     a.partial = nullptr;
     a.n_out_pad = tiles * TM;
     const long long wgs = (long long)tiles * ngroups;
-    static const int split_target = getenv("PBN_CONV_SPLIT") ? atoi(getenv("PBN_CONV_SPLIT")) : 256;
-    if (workspace && wgs < split_target / 2 && n_groups >= 8) {
-        long long want = (split_target + wgs - 1) / wgs;
+    // Split-K by a two-term cost model (microseconds, fitted on the bench scene's stride-4..16 levels):
+    //   a workgroup's chain of n_groups/ks groups at ~t_group each  +  ks fp32 partial slabs written and read back.
+    // The minimum is at ks* = sqrt(n_groups * t_group / slab_cost); more workgroups than ~2 per CU only queue up.
+    static const float t_group = getenv("PBN_CONV_TGROUP") ? (float)atof(getenv("PBN_CONV_TGROUP")) : 1.5f;
+    static const int max_wgs = getenv("PBN_CONV_SPLIT") ? atoi(getenv("PBN_CONV_SPLIT")) : 512;
+    if (workspace && wgs < 256 && n_groups >= 8) {
+        const float slab_us = 2.0f * (float)a.n_out_pad * (float)(a.ntiles_total * 16) * 4.0f / 3.0e6f;   // ~3 TB/s
+        long long want = (long long)(sqrtf((float)n_groups * t_group / (slab_us > 0.05f ? slab_us : 0.05f)) + 0.5f);
         const long long by_steps = n_groups / 2;
         const long long by_ws = (long long)(workspace_bytes / ((size_t)a.n_out_pad * a.ntiles_total * 16 * sizeof(float)));
+        const long long by_wgs = (RING == 3 ? 256 : max_wgs) / wgs;
+        if (want > by_wgs) want = by_wgs;
         if (want > by_steps) want = by_steps;
         if (want > by_ws) want = by_ws;
         if (want > 32) want = 32;
@@ -518,8 +526,14 @@ int launch_ring(ConvArgs a, int ngroups, float* workspace, size_t workspace_byte
 
 template <typename T, int NF, int NT>
 int launch_one(const ConvArgs& a, int ngroups, float* ws, size_t wsb, hipStream_t stream) {
-    // RING = 3 (two weight tiles in flight) was measured slower on every level of the bench scene: the third slot costs
-    // a workgroup per CU and the chains are not DMA-latency bound.  The template parameter stays for re-tuning.
+    // RING = 3 (two weight tiles in flight): experiment switch PBN_CONV_RING=3 for the small levels (< 8k rows)
+    static const int ring_env = getenv("PBN_CONV_RING") ? atoi(getenv("PBN_CONV_RING")) : 2;
+    if constexpr (NF == 1) {
+        if (ring_env == 3 && a.n_out < 8192) {
+            const int rc = launch_ring<T, NF, NT, 3>(a, ngroups, ws, wsb, stream);
+            if (rc != PBN_ERR_UNSUPPORTED) return rc;
+        }
+    }
     return launch_ring<T, NF, NT, 2>(a, ngroups, ws, wsb, stream);
 }
 
