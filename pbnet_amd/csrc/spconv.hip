@@ -596,7 +596,7 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, const int32_t*
     a.dbg = dbg_env;
     float* ws = reinterpret_cast<float*>(workspace);
     if (((uintptr_t)workspace) & 15) ws = nullptr;
-    if (rows_per_wave != 16 && rows_per_wave != 32 && rows_per_wave != 64) rows_per_wave = (n_out >= 8 * 1024) ? 32 : 16;
+    if (rows_per_wave != 16 && rows_per_wave != 32 && rows_per_wave != 64) rows_per_wave = (n_out > 64) ? 32 : 16;
     switch (dtype) {
         case PBN_F32: return launch_t<float>(a, rows_per_wave, ws, workspace_bytes, stream);
         case PBN_BF16: return launch_t<__hip_bfloat16>(a, rows_per_wave, ws, workspace_bytes, stream);
