@@ -165,6 +165,7 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     int* s_grp = s_valid + ((K + 3) & ~3);                                          // n_groups + 4 (entry n_groups = count)
     int* s_masks = s_grp + n_groups + 4;                                            // n_groups + 4 fragment masks
     int* s_gko = s_masks + n_groups + 4;                                            // n_groups + 4: offset | sub-group << 16
+    float* s_ss = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(s_gko + n_groups + 4) + 15) & ~(uintptr_t)15);  // scale | shift
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform for the compiler
@@ -174,6 +175,12 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     const int tile0 = blockIdx.y * NT;
 
     for (int k = tid; k < K; k += CONV_TPB) s_valid[k] = 0;
+    // epilogue constants of this workgroup's NT*16 output channels -> LDS (read back after the reduction)
+    if (a.ksplit == 1 && tid < NT * 32) {
+        const int c = tile0 * 16 + (tid < NT * 16 ? tid : tid - NT * 16);
+        const float* src = tid < NT * 16 ? a.scale : a.shift;
+        s_ss[tid] = src ? src[c] : (tid < NT * 16 ? 1.0f : 0.0f);
+    }
     // rulebook tile -> LDS.  Full tiles of an un-permuted launch are one contiguous, 16-byte aligned block of TM*K
     // ints: copied with independent 16-byte loads; otherwise element-wise (float-reciprocal division, exact here).
     if (a.nbr && !a.row_perm && row0 + TM <= n && KS == K && ((TM * K) & 3) == 0) {
@@ -425,11 +432,11 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
             const int c0 = (tile0 + t) * 16 + g * 4;
             f32x4 v = acc[f][t];
             if (a.scale) {
-                const float4 sc = *reinterpret_cast<const float4*>(a.scale + c0);
+                const float4 sc = *reinterpret_cast<const float4*>(s_ss + t * 16 + g * 4);
                 v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
             }
             if (a.shift) {
-                const float4 sh = *reinterpret_cast<const float4*>(a.shift + c0);
+                const float4 sh = *reinterpret_cast<const float4*>(s_ss + NT * 16 + t * 16 + g * 4);
                 v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
             }
             if (res) {
@@ -486,7 +493,8 @@ int launch_ring(ConvArgs a, int ngroups, float* workspace, size_t workspace_byte
             if (spo % c == 0) { a.cg = c; break; }
     }
     const int n_groups = a.n_steps / a.cg;
-    const size_t lds = (size_t)RING * a.cg * NT * 1024 + sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 3 * ((size_t)n_groups + 4));
+    const size_t lds = (size_t)RING * a.cg * NT * 1024 +
+                       sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 3 * ((size_t)n_groups + 4) + 2 * NT * 16 + 4);
     if (lds > 160 * 1024) return PBN_ERR_UNSUPPORTED;
     auto kern = k_spconv<T, NF, NT, RING>;
     if (lds > 64 * 1024)
