@@ -258,6 +258,27 @@ size_t pbn_coords_arena_bytes(int n, int want_k5, pbn_coords_layout* layout);
 int pbn_coords_build(const int32_t* coords, const int32_t* n_dev, int n, int want_k5, int x_fastest, void* arena,
                      size_t arena_bytes, const pbn_coords_layout* layout, pbn_stream_t stream);
 
+/* pbn_coords_prepare: what constructing a SparseTensor and expanding its lineage in Z-order takes, in ONE call
+ * (network/PBNet.py:117,240-247,265-271 reach this through ME.SparseTensor): de-duplication of the input rows (first
+ * occurrence wins, survivors in ascending input order = the external row order), Z-order sort of the survivors, and the
+ * pbn_coords_build expansion of the sorted rows.  Everything lives in one caller-owned arena:
+ *   pyramid       the sorted lineage exactly as pbn_coords_build lays it out (counts[0..4] = rows per level, -1 on a
+ *                 coordinate range error)
+ *   n_unique      int32: survivors (= counts[0])
+ *   unique_index  int64[n]: external row -> input row          inverse   int64[n]: input row -> external row
+ *   perm          int64[n]: sorted position -> external row    inv_perm  int64[n]: external row -> sorted position
+ *   ucoords       int32[n,4]: survivor coordinates in the external order
+ * (only the first n_unique entries of the per-survivor arrays are meaningful; the rest of the struct is scratch). */
+typedef struct {
+    pbn_coords_layout pyramid;
+    int64_t n_unique, unique_index, inverse, perm, inv_perm, ucoords;
+    int64_t tmp_keys, tmp_vals, uidx32, inv32, sort_keys, sort_vals, sort_temp, sort_temp_bytes;
+} pbn_prepare_layout;
+
+size_t pbn_coords_prepare_bytes(int n, int want_k5, pbn_prepare_layout* layout);
+int pbn_coords_prepare(const int32_t* coords, int n, int want_k5, int x_fastest, void* arena, size_t arena_bytes,
+                       const pbn_prepare_layout* layout, pbn_stream_t stream);
+
 /* Z-order keys (batch-major, then bit-interleaved x, y, z) of coordinate rows; rows at or beyond *n_dev get the largest
  * key.  Sorting rows by this key turns every run of consecutive rows into a compact spatial block: convolution tiles
  * then drop whole offset groups and their gathers stay inside one XCD's L2. */

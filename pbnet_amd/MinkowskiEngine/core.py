@@ -41,15 +41,20 @@ class _Pyramid(object):
     device-resident row counts."""
     _STRIDES = (1, 2, 4, 8, 16)
 
-    def __init__(self, coords, n_dev, n_cap):
+    def __init__(self, coords, n_dev, n_cap, _prepared=None):
         lib = N.lib()
-        self.device = coords.device
-        self.layout = N.CoordsLayout()
-        nbytes = lib.pbn_coords_arena_bytes(n_cap, 1, ctypes.byref(self.layout))
-        self.arena = torch.empty(nbytes, dtype=torch.uint8, device=coords.device)
-        rc = lib.pbn_coords_build(N.ptr(coords), None if n_dev is None else N.ptr(n_dev), n_cap, 1, int(CV.X_FASTEST),
-                                  N.ptr(self.arena), nbytes, ctypes.byref(self.layout), N.current_stream())
-        N.check(rc, "pbn_coords_build")
+        if _prepared is not None:           # (arena, layout) already filled by pbn_coords_prepare
+            self.arena, self.layout = _prepared
+            self.device = self.arena.device
+        else:
+            self.device = coords.device
+            self.layout = N.CoordsLayout()
+            nbytes = lib.pbn_coords_arena_bytes(n_cap, 1, ctypes.byref(self.layout))
+            self.arena = torch.empty(nbytes, dtype=torch.uint8, device=coords.device)
+            rc = lib.pbn_coords_build(N.ptr(coords), None if n_dev is None else N.ptr(n_dev), n_cap, 1,
+                                      int(CV.X_FASTEST), N.ptr(self.arena), nbytes, ctypes.byref(self.layout),
+                                      N.current_stream())
+            N.check(rc, "pbn_coords_build")
         self.counts_dev = self.view(self.layout.counts, 5, torch.int32)
         self.n = None
 
@@ -138,6 +143,25 @@ class CoordinateManager(object):
         self._final = False
         self.unique_index = self.inverse_mapping = self.is_identity = None
         self._n1 = None
+        if prepare is None:
+            prepare = ("plain" if torch.is_grad_enabled() else "sorted") if build_maps else "unique"
+        self._native = None
+        if prepare == "sorted" and n > 0:
+            # inference: de-duplication + Z-order + pyramid + maps in ONE native call (pbn_coords_prepare)
+            P = N.PrepareLayout()
+            nbytes = lib.pbn_coords_prepare_bytes(n, 1, ctypes.byref(P))
+            arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            rc = lib.pbn_coords_prepare(N.ptr(coords), n, 1, int(CV.X_FASTEST), N.ptr(arena), nbytes, ctypes.byref(P),
+                                        N.current_stream())
+            N.check(rc, "pbn_coords_prepare")
+            self._native = (arena, P)
+            sv = SortedView()
+            sv.pyramid = _Pyramid(None, None, n, _prepared=(arena, P.pyramid))
+            sv.perm = sv.inv_perm = None
+            self._sorted = sv
+            self._count = sv.pyramid.view(P.n_unique, 1, torch.int32)
+            self._ucoords = sv.pyramid.view(P.ucoords, max(n, 1) * 4, torch.int32, (max(n, 1), 4))
+            return
         cap = lib.pbn_hash_capacity(n)
         keys = torch.empty(cap, dtype=torch.int64, device=dev)
         vals = _i32(cap, dev)
@@ -150,8 +174,6 @@ class CoordinateManager(object):
                                    N.ptr(self._inv), N.ptr(self._ucoords), N.ptr(self._count), N.ptr(ws), wsb,
                                    N.current_stream())
         N.check(rc, "pbn_coords_unique")
-        if prepare is None:
-            prepare = ("plain" if torch.is_grad_enabled() else "sorted") if build_maps else "unique"
         if prepare == "plain":
             self._build_plain()
         elif prepare == "sorted":
@@ -179,6 +201,22 @@ class CoordinateManager(object):
 
     def _finalize(self):
         if self._final:
+            return
+        if self._native is not None:
+            arena, P = self._native
+            pyr = self._sorted.pyramid
+            counts = pyr.counts_dev.tolist()                                           # the one host read
+            if counts[0] < 0:
+                raise ValueError("coordinate out of range: batch must be in [0,65534], x/y/z in [-32768,32767]")
+            pyr.set_counts(counts)
+            n1 = self._n1 = int(counts[0])
+            n = self.n_input
+            self.unique_index = pyr.view(P.unique_index, n, torch.int64)[:n1]
+            self.inverse_mapping = pyr.view(P.inverse, n, torch.int64)
+            self.is_identity = (n1 == n)
+            self._sorted.perm = pyr.view(P.perm, n, torch.int64)[:n1]
+            self._sorted.inv_perm = pyr.view(P.inv_perm, n, torch.int64)[:n1]
+            self._final = True
             return
         pending = [p for p in (self._plain, self._sorted.pyramid if self._sorted else None) if p is not None and p.n is None]
         counts = torch.cat([self._count] + [p.counts_dev for p in pending]).tolist()   # the one host read

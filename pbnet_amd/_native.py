@@ -31,6 +31,14 @@ class CoordsLayout(ctypes.Structure):
                 ("capacity", c_i32 * 5), ("_pad", c_i32)]
 
 
+class PrepareLayout(ctypes.Structure):
+    """pbn_prepare_layout (include/pbnet_hip.h)."""
+    _fields_ = [("pyramid", CoordsLayout), ("n_unique", c_i64), ("unique_index", c_i64), ("inverse", c_i64),
+                ("perm", c_i64), ("inv_perm", c_i64), ("ucoords", c_i64), ("tmp_keys", c_i64), ("tmp_vals", c_i64),
+                ("uidx32", c_i64), ("inv32", c_i64), ("sort_keys", c_i64), ("sort_vals", c_i64), ("sort_temp", c_i64),
+                ("sort_temp_bytes", c_i64)]
+
+
 class UnetOp(ctypes.Structure):
     """pbn_unet_op (include/pbnet_hip.h)."""
     _fields_ = [("map_kind", c_i32), ("level_in", c_i32), ("level_out", c_i32),
@@ -82,6 +90,8 @@ SIGNATURES = {
     "pbn_kernel_map_cube": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_coords_arena_bytes": (c_size, [c_int, c_int, ctypes.POINTER(CoordsLayout)]),
     "pbn_coords_build": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(CoordsLayout), c_vp]),
+    "pbn_coords_prepare_bytes": (c_size, [c_int, c_int, ctypes.POINTER(PrepareLayout)]),
+    "pbn_coords_prepare": (c_int, [c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(PrepareLayout), c_vp]),
     "pbn_morton_keys": (c_int, [c_i32p, c_i32p, c_int, c_vp, c_vp]),
     "pbn_unet_arena_bytes": (c_size, [ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32), c_int,
                                       ctypes.POINTER(c_i64)]),

@@ -480,3 +480,79 @@ extern "C" int pbn_morton_keys(const int32_t* coords, const int32_t* n_dev, int 
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
+
+// ---- internals for the one-call prepare path (prepare.hip) -----------------------------------------------------------
+namespace pbn {
+namespace {
+// level-0 table of rows that are already unique: value = row id, coordinates copied, no numbering pass
+__global__ __launch_bounds__(TPB) void k_insert_identity(const int* __restrict__ coords, const int* n_dev, int n_max,
+                                                        unsigned long long* __restrict__ keys, int* __restrict__ vals,
+                                                        unsigned mask, int* __restrict__ out_coords,
+                                                        int* __restrict__ n_out) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    const int n = real_n(n_dev, n_max);
+    if (i == 0) *n_out = n_dev ? *n_dev : n_max;      // keeps a -1 (range error) visible
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    reinterpret_cast<int4*>(out_coords)[i] = c;
+    unsigned h = hash64(pack4(c.x, c.y, c.z, c.w)) & mask;
+    const unsigned long long key = pack4(c.x, c.y, c.z, c.w);
+    while (atomicCAS(&keys[h], EMPTY_KEY, key) != EMPTY_KEY) h = (h + 1) & mask;
+    vals[h] = i;
+}
+
+__global__ __launch_bounds__(TPB) void k_morton_iota(const int* __restrict__ coords, const int* n_dev, int n_max,
+                                                    unsigned long long* __restrict__ keys, int* __restrict__ iota) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n_max) return;
+    iota[i] = i;
+    if (i >= real_n(n_dev, n_max)) { keys[i] = 0x7fffffffffffffffULL; return; }  // padding rows sort to the end
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    const unsigned long long m = spread3((unsigned)(c.y + 32768)) | (spread3((unsigned)(c.z + 32768)) << 1) |
+                                 (spread3((unsigned)(c.w + 32768)) << 2);
+    keys[i] = (((unsigned long long)(unsigned)c.x & 0x7fffULL) << 48) | (m & 0xffffffffffffULL);
+}
+
+// sorted coordinates + the permutation pair, and the 64-bit copies of the de-duplication maps (torch indexes with int64)
+__global__ __launch_bounds__(TPB) void k_apply_perm(const int* __restrict__ ucoords, const int* __restrict__ perm32,
+                                                   const int* __restrict__ uidx32, const int* __restrict__ inv32, int n_max,
+                                                   int* __restrict__ sorted_coords, long long* __restrict__ perm64,
+                                                   long long* __restrict__ inv_perm64, long long* __restrict__ uidx64,
+                                                   long long* __restrict__ inv64) {
+    const int j = blockIdx.x * TPB + threadIdx.x;
+    if (j >= n_max) return;
+    const int r = perm32[j];
+    reinterpret_cast<int4*>(sorted_coords)[j] = reinterpret_cast<const int4*>(ucoords)[r];
+    perm64[j] = r;
+    inv_perm64[r] = j;
+    uidx64[j] = uidx32[j];
+    inv64[j] = inv32[j];
+}
+}  // namespace
+
+int coords_insert_identity(const int32_t* coords, const int32_t* n_dev, int n_max, uint64_t* keys, int32_t* vals,
+                           int capacity, int32_t* out_coords, int32_t* n_out, hipStream_t stream) {
+    if (n_max <= 0) return PBN_OK;
+    hipLaunchKernelGGL(k_insert_identity, dim3(cdiv(n_max, TPB)), dim3(TPB), 0, stream, coords, n_dev, n_max,
+                       (unsigned long long*)keys, vals, (unsigned)capacity - 1, out_coords, n_out);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+int coords_morton_iota(const int32_t* coords, const int32_t* n_dev, int n_max, uint64_t* keys, int32_t* iota,
+                       hipStream_t stream) {
+    if (n_max <= 0) return PBN_OK;
+    hipLaunchKernelGGL(k_morton_iota, dim3(cdiv(n_max, TPB)), dim3(TPB), 0, stream, coords, n_dev, n_max,
+                       (unsigned long long*)keys, iota);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+int coords_apply_perm(const int32_t* ucoords, const int32_t* perm32, const int32_t* uidx32, const int32_t* inv32, int n_max,
+                      int32_t* sorted_coords, int64_t* perm64, int64_t* inv_perm64, int64_t* uidx64, int64_t* inv64,
+                      hipStream_t stream) {
+    if (n_max <= 0) return PBN_OK;
+    hipLaunchKernelGGL(k_apply_perm, dim3(cdiv(n_max, TPB)), dim3(TPB), 0, stream, ucoords, perm32, uidx32, inv32, n_max,
+                       sorted_coords, (long long*)perm64, (long long*)inv_perm64, (long long*)uidx64, (long long*)inv64);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+}  // namespace pbn

@@ -61,6 +61,18 @@ extern "C" int pbn_coords_build(const int32_t* coords, const int32_t* n_dev, int
                                 I(L->unique_index), I(L->inverse), I(L->coords[0]), counts + 0, ws, wsb, counts + 8, false,
                                 st);
     if (rc != PBN_OK) return rc;
+    return coords_build_upper(n, want_k5, x_fastest, arena, L, st);
+}
+
+// levels 1..4, the k=3 maps of all levels, the k=5 map of level 0: level 0 (coords, table, count) must be finished and
+// the fill-pattern groups of the arena cleared
+int pbn::coords_build_upper(int n, int want_k5, int x_fastest, void* arena, const pbn_coords_layout* L, hipStream_t st) {
+    char* A = (char*)arena;
+    auto I = [&](int64_t o) { return (int32_t*)(A + o); };
+    int32_t* counts = I(L->counts);
+    void* ws = A + L->workspace;
+    const size_t wsb = (size_t)L->workspace_bytes;
+    int rc = PBN_OK;
     for (int l = 0; l < 4; ++l) {
         rc = coords_stride_impl(I(L->coords[l]), counts + l, n, 2 << l, (uint64_t*)(A + L->keys[l + 1]), I(L->vals[l + 1]),
                                 L->capacity[l + 1], I(L->coords[l + 1]), I(L->parent_row[l]), I(L->child_k[l]),
@@ -69,15 +81,85 @@ extern "C" int pbn_coords_build(const int32_t* coords, const int32_t* n_dev, int
     }
     for (int l = 0; l < 5; ++l) {
         rc = pbn_kernel_map_cube(I(L->coords[l]), counts + l, n, 3, 1 << l, x_fastest, (const uint64_t*)(A + L->keys[l]),
-                                 I(L->vals[l]), L->capacity[l], I(L->k3[l]), stream);
+                                 I(L->vals[l]), L->capacity[l], I(L->k3[l]), st);
         if (rc != PBN_OK) return rc;
     }
     if (want_k5) {
         rc = pbn_kernel_map_cube(I(L->coords[0]), counts + 0, n, 5, 1, x_fastest, (const uint64_t*)(A + L->keys[0]),
-                                 I(L->vals[0]), L->capacity[0], I(L->k5), stream);
+                                 I(L->vals[0]), L->capacity[0], I(L->k5), st);
         if (rc != PBN_OK) return rc;
     }
     return PBN_OK;
+}
+
+// ---- pbn_coords_prepare: de-duplication, Z-order, pyramid and maps of one SparseTensor lineage in ONE call -----------
+extern "C" size_t pbn_coords_prepare_bytes(int n, int want_k5, pbn_prepare_layout* P) {
+    if (n < 0 || !P) return 0;
+    const size_t N = (size_t)(n > 0 ? n : 1);
+    const size_t pyr = pbn_coords_arena_bytes(n, want_k5, &P->pyramid);
+    if (!pyr) return 0;
+    size_t off = a256(pyr);
+    auto take = [&](size_t bytes) { size_t o = off; off = a256(off + bytes); return (int64_t)o; };
+    const int cap = pbn_hash_capacity(n);
+    P->n_unique = take(16 * sizeof(int));               // [0] survivors (or -1), [8] range-error status
+    P->tmp_keys = take((size_t)cap * 8);
+    P->tmp_vals = take((size_t)cap * 4);
+    P->unique_index = take(N * 8);
+    P->inverse = take(N * 8);
+    P->perm = take(N * 8);
+    P->inv_perm = take(N * 8);
+    P->ucoords = take(N * 16);
+    P->uidx32 = take(N * 4);
+    P->inv32 = take(N * 4);
+    P->sort_keys = take(2 * N * 8);
+    P->sort_vals = take(2 * N * 4);
+    P->sort_temp_bytes = (int64_t)sort_pairs_temp_bytes(n);
+    P->sort_temp = take((size_t)P->sort_temp_bytes);
+    return off;
+}
+
+extern "C" int pbn_coords_prepare(const int32_t* coords, int n, int want_k5, int x_fastest, void* arena, size_t arena_bytes,
+                                  const pbn_prepare_layout* P, pbn_stream_t stream) {
+    if (n < 0 || !arena || !P) return PBN_ERR_ARG;
+    pbn_prepare_layout chk;
+    if (pbn_coords_prepare_bytes(n, want_k5, &chk) > arena_bytes) return PBN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* A = (char*)arena;
+    const pbn_coords_layout* L = &P->pyramid;
+    auto I = [&](int64_t o) { return (int32_t*)(A + o); };
+    const size_t N = (size_t)(n > 0 ? n : 1);
+    // clears: the temporary table + the pyramid's three fill-pattern groups
+    PBN_HIP_CHECK(hipMemsetAsync(A + P->n_unique, 0, 16 * sizeof(int), st));
+    PBN_HIP_CHECK(hipMemsetAsync(A + P->tmp_keys, 0xff, (size_t)(P->tmp_vals - P->tmp_keys), st));
+    PBN_HIP_CHECK(hipMemsetAsync(A + P->tmp_vals, 0x7f, (size_t)(P->unique_index - P->tmp_vals), st));
+    PBN_HIP_CHECK(hipMemsetAsync(A + L->counts, 0, 16 * sizeof(int), st));
+    PBN_HIP_CHECK(hipMemsetAsync(A + L->keys[0], 0xff, (size_t)(L->vals[0] - L->keys[0]), st));
+    PBN_HIP_CHECK(hipMemsetAsync(A + L->vals[0], 0x7f, (size_t)(L->unique_index - L->vals[0]), st));
+    if (n == 0) return PBN_OK;
+    if (!coords) return PBN_ERR_ARG;
+    int32_t* n_unique = I(P->n_unique);
+    // 1. de-duplication in the external (first occurrence, ascending) order
+    int rc = coords_unique_impl(coords, nullptr, n, (uint64_t*)(A + P->tmp_keys), I(P->tmp_vals), pbn_hash_capacity(n),
+                                I(P->uidx32), I(P->inv32), I(P->ucoords), n_unique, A + L->workspace,
+                                (size_t)L->workspace_bytes, n_unique + 8, false, st);
+    if (rc != PBN_OK) return rc;
+    // 2. Z-order: keys, stable radix sort of (key, row), permutation pair + sorted coordinates
+    uint64_t* keys = (uint64_t*)(A + P->sort_keys);
+    int32_t* vals = I(P->sort_vals);
+    rc = coords_morton_iota(I(P->ucoords), n_unique, n, keys, vals, st);
+    if (rc != PBN_OK) return rc;
+    rc = sort_pairs_u64_i32(keys, keys + N, vals, vals + N, n, A + P->sort_temp, (size_t)P->sort_temp_bytes, st);
+    if (rc != PBN_OK) return rc;
+    rc = coords_apply_perm(I(P->ucoords), vals + N, I(P->uidx32), I(P->inv32), n, I(L->coords[0]),
+                           (int64_t*)(A + P->perm), (int64_t*)(A + P->inv_perm), (int64_t*)(A + P->unique_index),
+                           (int64_t*)(A + P->inverse), st);
+    if (rc != PBN_OK) return rc;
+    // 3. level 0 of the Z-ordered lineage: rows are unique already -> plain insert, value = row
+    rc = coords_insert_identity(I(L->coords[0]), n_unique, n, (uint64_t*)(A + L->keys[0]), I(L->vals[0]), L->capacity[0],
+                                I(L->coords[0]), I(L->counts), st);
+    if (rc != PBN_OK) return rc;
+    // 4. levels 1..4 and every map
+    return coords_build_upper(n, want_k5, x_fastest, arena, L, st);
 }
 
 static inline int esize(int dtype) { return dtype == PBN_F32 ? 4 : 2; }
