@@ -15,7 +15,8 @@ step    : one PBNet.forward over one scene per rank.  N > 1: every rank owns a d
 Also on the JSON line:
   roofline     -- the dominant kernel family (k_spconv, csrc/spconv.hip): algorithmic bytes of every launch (SURVEY.md
                   8d: (V_in*C_in + V_out*C_out)*b + K*C_in*C_out*b + 8*P) divided by that launch's duration, measured
-                  with HIP events on the launching stream in an instrumented pass over the same steps.
+                  with HIP events on the launching stream in an instrumented pass over the same steps; `traffic` is the
+                  HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_summary.json).
   cpu_baseline -- the CPU oracle (oracle/, a restatement: the reference's own CPU path cannot be installed) timed on
                   the host cores of rank 0 at N=1 on one full scene of the same workload.
 """
@@ -138,6 +139,20 @@ class ConvProbe(object):
         return self.launches, self.ms, self.nbytes, self.flops
 
 
+def pmc_traffic(args):
+    """HBM bytes per k_spconv launch from the committed PMC summary (profiles/r01_pmc_summary.json: two rocprofv3 --pmc
+    passes over this same command line, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).
+    Counters cannot be read from inside the process, so the number is only reported for the configuration it was
+    collected on (default workload, bf16, 1 copy); anything else -> null."""
+    if args.copies != 1 or args.dtype != "bf16":
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            return int(json.load(f)["k_spconv_traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, model, raw):
     """Oracle (kind "port") on the host cores: one full scene of the same workload."""
     from oracle import pbnet_ref
@@ -219,7 +234,7 @@ def main():
         probe.remove()
         achieved = nbytes / (t_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args), "kernel": "k_spconv",
                 "launches_per_step": n_launch // max(2, min(args.steps, 5)),
                 "avg_launch_us": round(t_ms * 1e3 / n_launch, 2),
                 "algorithmic_bytes_per_launch": int(nbytes / n_launch),
