@@ -12,13 +12,14 @@ What differs is WHERE things run, not what is computed:
   * get_proposal (PBNet.py:317-347) is a device compaction instead of Python loops.
 One host synchronisation per stage boundary (class counts, cluster table, proposal count), none per class/cluster.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
 from .. import MinkowskiEngine as ME
 from .. import pbnet_ops
 from .. import stage_ops
-from ..prof import section
+from ..prof import section, mark
 from .Mink import Mink_unet as unet3d
 
 COUNT_MEAN = [-1., -1., 3917., 12056., 2303., 8331., 3948., 3166., 5629., 11719., 1003., 3317., 4912., 10221., 3889.,
@@ -151,22 +152,29 @@ class PBNet(nn.Module):
         else:
             batch_head_p = s1["batch_head_p"].long()
             table = torch.bincount(sem_pred_p * nb + batch_head_p, minlength=n_cls * nb)[:n_cls * nb].view(n_cls, nb)
-        table_h = table.cpu()                                                     # sync 1
-        assert int(table_h.sum()) == sem_pred_p.shape[0], "batch index outside [0, cluster_batch)"  # PBNet.py:286
-        per_class = table_h.sum(1)
-        classes = [c for c in range(2, n_cls) if not (float(per_class[c]) < float(self.count_mean[c] * 0.05))]
+        mark("a6:before table sync")
+        tab = table.cpu().numpy()                                                 # sync 1
+        mark("a6:table on host")
+        assert int(tab.sum()) == sem_pred_p.shape[0], "batch index outside [0, cluster_batch)"  # PBNet.py:286
+        per_class = tab.sum(1).tolist()
+        thr05, thr02 = self._class_thresholds()
+        classes = [c for c in range(2, n_cls) if not (float(per_class[c]) < thr05[c])]          # PBNet.py:157
         if not classes:
             return self._empty_stage(dev, task)
-        m = int(per_class[classes].sum())
+        m = sum(per_class[c] for c in classes)
+        seg_len_h = tab[classes].reshape(-1).astype(np.int32)                    # segments = (class, batch) in order
         if fused:
-            # stable class-major selection + the grouping inputs in one launch (positions from the class totals)
-            class_base = torch.full((n_cls,), -1, dtype=torch.int32)
+            # stable class-major selection + the grouping inputs in one launch (positions from the class totals);
+            # class_base and the segment lengths travel in ONE host->device copy
+            class_base = np.full(n_cls, -1, dtype=np.int32)
             run = 0
             for c in classes:
                 class_base[c] = run
-                run += int(per_class[c])
+                run += per_class[c]
+            up = torch.from_numpy(np.concatenate([class_base, seg_len_h])).to(dev)
+            seg_len = up[n_cls:]
             ins_ind, ins_orig, ins_offseted, ins_sem = stage_ops.select_points(
-                sem_pred_p, class_base.to(dev), s1["block_hist"], xyz_original, offset_pred_p, m)
+                sem_pred_p, up[:n_cls], s1["block_hist"], xyz_original, offset_pred_p, m)
         else:
             keep = torch.zeros(n_cls, dtype=torch.bool)
             keep[classes] = True
@@ -176,40 +184,47 @@ class PBNet(nn.Module):
             ins_orig = xyz_original[ins_ind]
             ins_offseted = ins_orig + offset_pred_p[ins_ind].float()                 # PBNet.py:165 (fp32 add)
             ins_sem = sem_pred_p[ins_ind].to(torch.int32)
-        seg_len = table[classes].reshape(-1).to(torch.int32)                      # segments = (class, batch) in order
+            seg_len = torch.from_numpy(seg_len_h).to(dev)
         _sec.__exit__(None, None, None)
 
+        mark("a7:select queued")
         with section("a7_16_grouping"):
             res = pbnet_ops.cluster_device(ins_offseted, ins_orig, ins_sem, seg_len, self.radius, self.min_pts)
-            head = torch.cat([res.n_clusters, res.cluster_num]).cpu()                # sync 2
+            mark("a7:grouping queued")
+            head = torch.cat([res.n_clusters, res.cluster_num]).cpu().numpy()        # sync 2
+            mark("a7:grouping done")
             n_clt = int(head[0])
         if n_clt < 0:
             raise RuntimeError("grouping rejected its input (class id outside [2,19])")
         if n_clt == 0:
             return self._empty_stage(dev, task)
         _sec = section("a17_plan"); _sec.__enter__()
-        cluster_num = head[1:].view(len(classes), nb)
+        cluster_num = head[1:].reshape(len(classes), nb).tolist()
         packed = torch.cat([res.centers[:3 * n_clt], res.member_start[:n_clt + 1].view(torch.float32)]).cpu()  # sync 3
+        mark("a17:centres on host")
         centers = packed[:3 * n_clt].view(n_clt, 3)
-        member_start = packed[3 * n_clt:].view(torch.int32)
+        member_start = packed[3 * n_clt:].view(torch.int32).numpy()
         sizes = (member_start[1:] - member_start[:-1])
+        sizes_l = sizes.tolist()
         labels_h = None
         if task != "test":
             labels_h = ins_label[ins_ind[res.member_idx[:int(member_start[-1])].long()]].cpu()
 
         # (a17) host plan over clusters: which clusters make up each local scene, and with which weight
         ent_cluster, ent_weight, scene_len, scene_gt = [], [], [], []
+        k_max = self._k_max_list()
         g = 0                                                   # running global cluster id (class-major, batch, seed)
         for ci, cls in enumerate(classes):
             for b in range(nb):
-                c_b = int(cluster_num[ci, b])
+                c_b = cluster_num[ci][b]
                 if c_b == 0:
                     continue
-                para_k = min(c_b - 1, int(self.K_max[cls]))
+                para_k = min(c_b - 1, k_max[cls])
                 if para_k > 0:
                     peak_v = [0.5 * ((para_k + 1) - p_i) / (para_k + 1) for p_i in range(para_k + 1)]
                     ctr = centers[g:g + c_b]
-                    knn_idx = torch.cdist(ctr, ctr).topk(k=c_b, dim=1, largest=False)[1]
+                    knn_idx = torch.cdist(ctr, ctr).topk(k=c_b, dim=1, largest=False)[1].tolist()
+                big = thr02[cls]
                 for c_i in range(c_b):
                     gid = g + c_i
                     gt = None
@@ -218,9 +233,10 @@ class PBNet(nn.Module):
                         if gt == -100:
                             continue
                     ents, wts = [gid], [1.0]
-                    if float(sizes[gid]) > float(self.count_mean[cls] * 0.2) and para_k > 0:
+                    if float(sizes_l[gid]) > big and para_k > 0:                  # PBNet.py:199
+                        row = knn_idx[c_i]
                         for k_i in range(para_k):
-                            ents.append(g + int(knn_idx[c_i, k_i + 1]))
+                            ents.append(g + row[k_i + 1])
                             wts.append(peak_v[k_i])
                     ent_cluster += ents
                     ent_weight += wts
@@ -231,24 +247,26 @@ class PBNet(nn.Module):
             return self._empty_stage(dev, task)
 
         _sec.__exit__(None, None, None)
+        mark("a17:plan done")
         # device gathers over points: rows of every local scene, in the reference's order
         _sec = section("a17_gather"); _sec.__enter__()
-        ent_cluster_t = torch.tensor(ent_cluster, dtype=torch.long)
-        ent_rows = sizes[ent_cluster_t]
+        ent_np = np.asarray(ent_cluster, dtype=np.int64)
         if not torch.is_grad_enabled():
             # inference: ONE launch (pbn_local_scene_rows) driven by one packed host->device copy of the entry table
             n_ent = len(ent_cluster)
-            row_start = torch.zeros(n_ent + 1, dtype=torch.int32)
-            row_start[1:] = torch.cumsum(ent_rows, 0)
+            row_start = np.zeros(n_ent + 1, dtype=np.int32)
+            np.cumsum(sizes[ent_np], out=row_start[1:])
             n_rows = int(row_start[-1])
-            ent_scene = torch.repeat_interleave(torch.arange(len(scene_len), dtype=torch.int32),
-                                                torch.tensor(scene_len))
-            packed = torch.cat([row_start, member_start[:-1][ent_cluster_t].to(torch.int32), ent_scene,
-                                torch.tensor(ent_weight, dtype=torch.float32).view(torch.int32)]).to(dev)
+            ent_scene = np.repeat(np.arange(len(scene_len), dtype=np.int32), scene_len)
+            packed = torch.from_numpy(np.concatenate([row_start, member_start[:-1][ent_np].astype(np.int32), ent_scene,
+                                                      np.asarray(ent_weight, dtype=np.float32).view(np.int32)])).to(dev)
             point_idx, row_scene, coords, feat = stage_ops.local_scene_rows(
                 packed, n_ent, n_rows, res.member_idx, ins_ind, xyz_original, LOCAL_VOXEL, point_feat_p, sem_sfp,
                 None if fused else sem_pred_p)
         else:
+            ent_cluster_t = torch.from_numpy(ent_np)
+            ent_rows = torch.from_numpy(sizes.astype(np.int64))[ent_cluster_t]
+            member_start = torch.from_numpy(member_start)
             ent_scene = torch.repeat_interleave(torch.arange(len(scene_len)), torch.tensor(scene_len))
             d = lambda t: t.to(dev)
             row_ent = torch.repeat_interleave(torch.arange(len(ent_cluster), device=dev), d(ent_rows))
@@ -267,6 +285,7 @@ class PBNet(nn.Module):
         out = {}
         _sec.__exit__(None, None, None)
 
+        mark("a17:rows queued")
         # (a18) mask branch
         with section("a18_mask_coords"):
             inputs_v2 = ME.SparseTensor(feat, coords)
@@ -281,6 +300,7 @@ class PBNet(nn.Module):
             gt_mask = (lab == gt_rows).long()
             gt_mask[lab == -100] = -1
             out["mask_scores"] = (mask_score, gt_mask.detach())
+        mark("a18:mask unet queued")
         coords3 = feat3 = None
         with section("a19_proposals"):
             if fused_glue:
@@ -289,6 +309,7 @@ class PBNet(nn.Module):
             else:
                 out["proposals"] = self.get_proposal(row_scene, point_idx, mask_score, n_scenes=len(scene_len))
 
+        mark("a19:proposals queued")
         # (a20) score branch
         proposals_idx, proposals_offset, _, _ = out["proposals"]
         if proposals_offset.shape[0] > 1:
@@ -321,7 +342,24 @@ class PBNet(nn.Module):
                         out["clt_scores"] = self.linear_IOU(_PooledTensor(pooled)).F.view(-1)
         else:
             out["clt_scores"] = torch.zeros(0, dtype=torch.float32, device=dev)
+        mark("a20:score branch queued")
         return out
+
+    def _class_thresholds(self):
+        """Per-class population gates as Python floats of the fp32 products (PBNet.py:157 `count_mean * 0.05`,
+        :199 `count_mean * 0.2`): computed once, with the same fp32 multiplication the per-element form performs."""
+        hit = getattr(self, "_thr_cache", None)
+        if hit is None:
+            hit = ((self.count_mean * 0.05).tolist(), (self.count_mean * 0.2).tolist())
+            self._thr_cache = hit
+        return hit
+
+    def _k_max_list(self):
+        hit = getattr(self, "_kmax_cache", None)
+        if hit is None:
+            hit = [int(v) for v in self.K_max.tolist()]
+            self._kmax_cache = hit
+        return hit
 
     def _empty_stage(self, dev, task):
         z = torch.zeros(0, dtype=torch.int64, device=dev)
@@ -338,17 +376,22 @@ class PBNet(nn.Module):
         (kept rows per local scene).  Same outputs as get_proposal; also returns (coords3, feat3)."""
         dev = row_scene.device
         per_scene_d, block_cnt = stage_ops.mask_count(mask_score, mask_score_thd, row_scene, n_scenes)
-        per_scene = per_scene_d.cpu().long()                                         # sync
+        mark("a19:before count sync")
+        per_scene = per_scene_d.cpu().numpy().astype(np.int64)                       # sync
+        mark("a19:counts on host")
         total = int(per_scene.sum())
         alive = per_scene > 0
-        cluster_id_v = torch.nonzero(alive).view(-1)                                # surviving scene ids (host)
-        proposals_offset = torch.zeros(int(alive.sum()) + 1, dtype=torch.int64)
-        proposals_offset[1:] = torch.cumsum(per_scene[alive], 0)
-        dense_of = (torch.cumsum(alive.to(torch.int32), 0) - 1).to(torch.int32)     # PBNet.py:342-345
+        n_alive = int(alive.sum())
+        proposals_offset = np.zeros(n_alive + 1, dtype=np.int64)
+        np.cumsum(per_scene[alive], out=proposals_offset[1:])
+        dense_of = (np.cumsum(alive) - 1).astype(np.int32)                          # PBNet.py:342-345
+        # proposals_offset | surviving scene ids in one copy, the renumbering (int32) in another
+        up64 = torch.from_numpy(np.concatenate([proposals_offset, np.nonzero(alive)[0].astype(np.int64)])).to(dev)
+        dense_of = torch.from_numpy(dense_of).to(dev)
         prop_idx, prop_ms, coords3, feat3 = stage_ops.proposal_rows(
-            mask_score, mask_score_thd, row_scene, point_idx, dense_of.to(dev), block_cnt, total, xyz_original,
+            mask_score, mask_score_thd, row_scene, point_idx, dense_of, block_cnt, total, xyz_original,
             self.scale_size, self.voxel_size, point_feat_p)
-        return (prop_idx, proposals_offset.to(dev), cluster_id_v.to(dev), prop_ms), coords3, feat3
+        return (prop_idx, up64[:n_alive + 1], up64[n_alive + 1:], prop_ms), coords3, feat3
 
     # ---- PBNet.py:317-347 as one device compaction ----------------------------------------------------------------
     def get_proposal(self, row_scene, point_idx, mask_score, mask_score_thd=MASK_THD, n_scenes=None):

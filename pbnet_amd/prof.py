@@ -37,3 +37,19 @@ def section(name):
 
 def report():
     return {k: (1e3 * v / COUNTS[k], COUNTS[k]) for k, v in TIMES.items()}
+
+
+# ---- host-side marks: wall-clock stamps WITHOUT device synchronisation (where does the Python thread spend its time) ----
+HOST_MARKS = None
+
+
+def host_marks(enable=True):
+    """Start (or stop) recording; returns the list that `mark` appends (name, perf_counter seconds) to."""
+    global HOST_MARKS
+    HOST_MARKS = [] if enable else None
+    return HOST_MARKS
+
+
+def mark(name):
+    if HOST_MARKS is not None:
+        HOST_MARKS.append((name, time.perf_counter()))
