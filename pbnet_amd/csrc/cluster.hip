@@ -143,51 +143,95 @@ __device__ __forceinline__ bool cell_trusted(int cx, int cy, int cz) {
 }
 
 // Enumerate the 5x5x5 cells around point (x,y,z) of segment seg; f(beg, end, slot, trusted, same) per occupied cell.
+// The 125 cells of a point are dealt round-robin to the `stride` lanes that share the point (lane `first` takes cells
+// first, first+stride, ...): the hash probes, not the distance tests, are what these sweeps spend their time on.
 template <typename F>
 __device__ __forceinline__ void for_each_neighbour_cell(float x, float y, float z, int seg, float inv_cell,
                                                         const unsigned long long* __restrict__ hkeys, unsigned hmask,
                                                         const int* __restrict__ hstart, const int* __restrict__ hcount,
-                                                        F&& f) {
+                                                        int first, int stride, F&& f) {
     const int cx = cell_coord(x, inv_cell), cy = cell_coord(y, inv_cell), cz = cell_coord(z, inv_cell);
-    for (int dz = -CELL_R; dz <= CELL_R; ++dz)
-        for (int dy = -CELL_R; dy <= CELL_R; ++dy)
-            for (int dx = -CELL_R; dx <= CELL_R; ++dx) {
-                const int slot = hash_lookup(hkeys, hmask, pack_key(seg, cx + dx, cy + dy, cz + dz));
-                if (slot < 0) continue;
-                const int beg = hstart[slot];
-                f(beg, beg + hcount[slot], slot, cell_trusted(cx + dx, cy + dy, cz + dz), (dx | dy | dz) == 0);
-            }
+    constexpr int W = 2 * CELL_R + 1;
+    for (int c = first; c < W * W * W; c += stride) {
+        const int dz = c / (W * W) - CELL_R, dy = (c / W) % W - CELL_R, dx = c % W - CELL_R;
+        const int slot = hash_lookup(hkeys, hmask, pack_key(seg, cx + dx, cy + dy, cz + dz));
+        if (slot < 0) continue;
+        const int beg = hstart[slot];
+        f(beg, beg + hcount[slot], slot, cell_trusted(cx + dx, cy + dy, cz + dz), (dx | dy | dz) == 0);
+    }
 }
 
-// ---- a10/a12: exact r-ball population (self excluded); FOUR adjacent lanes per cell-sorted position share the
-// candidate stream (lane q takes candidates beg+q, beg+q+4, ...) and combine with two shuffles
-constexpr int CNT_Q = 4;
+// ---- a10/a12: exact r-ball population (self excluded).  NB_Q adjacent lanes share one cell-sorted position: per round
+// every lane probes ONE of the 125 cells, then the group walks the found cells together, lane q taking candidates
+// beg+q, beg+q+NB_Q, ... (shifted coordinates pile up near instance centres: single cells hold hundreds of points)
+constexpr int NB_Q = 8;
+__device__ __forceinline__ bool group_any(bool pred) {
+    const unsigned long long m = __ballot(pred);
+    return ((m >> (threadIdx.x & 63 & ~(NB_Q - 1))) & ((1ULL << NB_Q) - 1ULL)) != 0ULL;
+}
+// f(beg, end, slot, trusted, same) is called by ALL lanes of the group for every occupied cell (group-uniform arguments)
+template <typename F>
+__device__ __forceinline__ void for_each_neighbour_cell_group(float x, float y, float z, int seg, float inv_cell,
+                                                              const unsigned long long* __restrict__ hkeys, unsigned hmask,
+                                                              const int* __restrict__ hstart,
+                                                              const int* __restrict__ hcount, int q, F&& f) {
+    const int cx = cell_coord(x, inv_cell), cy = cell_coord(y, inv_cell), cz = cell_coord(z, inv_cell);
+    constexpr int W = 2 * CELL_R + 1;
+    const int gbase = (threadIdx.x & 63) & ~(NB_Q - 1);
+    for (int r = 0; r < W * W * W; r += NB_Q) {
+        const int c = r + q;
+        int slot = -1, beg = 0, end = 0;
+        if (c < W * W * W) {
+            const int dz = c / (W * W) - CELL_R, dy = (c / W) % W - CELL_R, dx = c % W - CELL_R;
+            slot = hash_lookup(hkeys, hmask, pack_key(seg, cx + dx, cy + dy, cz + dz));
+            if (slot >= 0) { beg = hstart[slot]; end = beg + hcount[slot]; }
+        }
+#pragma unroll
+        for (int k = 0; k < NB_Q; ++k) {
+            const int sk = __shfl(slot, gbase + k, 64);
+            if (sk < 0) continue;
+            const int bk = __shfl(beg, gbase + k, 64), ek = __shfl(end, gbase + k, 64);
+            const int ck = r + k;
+            const int dz = ck / (W * W) - CELL_R, dy = (ck / W) % W - CELL_R, dx = ck % W - CELL_R;
+            f(bk, ek, sk, cell_trusted(cx + dx, cy + dy, cz + dz), (dx | dy | dz) == 0);
+        }
+    }
+}
+__device__ __forceinline__ int group_sum(int v) {
+#pragma unroll
+    for (int o = 1; o < NB_Q; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int group_max(int v) {
+#pragma unroll
+    for (int o = 1; o < NB_Q; o <<= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
 __global__ __launch_bounds__(TPB) void k_count(const float4* __restrict__ spt, const int* __restrict__ sseg, int n,
                                               float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
                                               unsigned hmask, const int* __restrict__ hstart,
                                               const int* __restrict__ hcount, int* __restrict__ den) {
     const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
-    int p = (int)(t / CNT_Q);
-    const int q = (int)(t % CNT_Q);
+    int p = (int)(t / NB_Q);
+    const int q = (int)(t % NB_Q);
     const bool live = p < n;
-    if (!live) p = n - 1;  // keep the quad complete for the shuffles
+    if (!live) p = n - 1;  // keep the lane group complete for the shuffles
     const float4 me = spt[p];
     int cnt = 0;
-    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount,
-                            [&](int beg, int end, int, bool, bool) {
+    for_each_neighbour_cell_group(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount, q,
+                                  [&](int beg, int end, int, bool, bool) {
         int j = beg + q;
-        for (; j + CNT_Q < end; j += 2 * CNT_Q) {  // two independent loads in flight
-            const float4 q0 = spt[j], q1 = spt[j + CNT_Q];
+        for (; j + NB_Q < end; j += 2 * NB_Q) {  // two independent loads in flight
+            const float4 q0 = spt[j], q1 = spt[j + NB_Q];
             cnt += (sqdist(me.x, me.y, me.z, q0.x, q0.y, q0.z) <= r2) ? 1 : 0;
             cnt += (sqdist(me.x, me.y, me.z, q1.x, q1.y, q1.z) <= r2) ? 1 : 0;
         }
-        for (; j < end; j += CNT_Q) {
+        for (; j < end; j += NB_Q) {
             const float4 q0 = spt[j];
             cnt += (sqdist(me.x, me.y, me.z, q0.x, q0.y, q0.z) <= r2) ? 1 : 0;
         }
     });
-    cnt += __shfl_xor(cnt, 1, 64);
-    cnt += __shfl_xor(cnt, 2, 64);
+    cnt = group_sum(cnt);
     if (live && q == 0) den[__float_as_int(me.w)] = cnt - 1;  // binary_cuda_functions.cu:88
 }
 
@@ -248,7 +292,10 @@ __global__ __launch_bounds__(TPB) void k_union(const float4* __restrict__ spt, c
     // (k_compress flattens the forest in between)
     // pass 1: every HP repeats the cross-cell search, which is now a cached parent compare for all merged pairs and
     //         only does real work for the edges a representative could not witness.
-    const int p = blockIdx.x * TPB + threadIdx.x;
+    // NB_Q lanes share a point and split its 125 cells; each lane keeps its own cached root (the forest is the only
+    // shared state and it is lock-free), which also shortens the serial chain of the few representatives of pass 0
+    const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
+    const int p = (int)(t / NB_Q), q = (int)(t % NB_Q);
     if (p >= n) return;
     const float4 me = spt[p];
     const int wi = __float_as_int(me.w);
@@ -258,9 +305,12 @@ __global__ __launch_bounds__(TPB) void k_union(const float4* __restrict__ spt, c
     const bool own_trusted = cell_trusted(cell_coord(me.x, inv_cell), cell_coord(me.y, inv_cell), cell_coord(me.z, inv_cell));
     int ri = (pass == 0) ? i : parent[i];
     if (pass == 0 && own_trusted) {
-        if (my_rep != i) { uf_union(parent, i, my_rep); return; }  // chained; the representative does the rest
+        if (my_rep != i) {  // chained; the representative does the rest
+            if (q == 0) uf_union(parent, i, my_rep);
+            return;
+        }
     }
-    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount,
+    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount, q, NB_Q,
                             [&](int beg, int end, int slot, bool trusted, bool same) {
         const int rep = cell_rep[slot];
         if (rep == BIG) return;  // no HP in that cell
@@ -336,11 +386,14 @@ __global__ __launch_bounds__(TPB) void k_border(const float4* __restrict__ spt, 
                                                const int* __restrict__ hcount, const int* __restrict__ sem, int general,
                                                const int* __restrict__ semseed, const int* __restrict__ root,
                                                int* __restrict__ lab, const int* __restrict__ cell_rep) {
-    const int p = blockIdx.x * TPB + threadIdx.x;
-    if (p >= n) return;
+    const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
+    int p = (int)(t / NB_Q);
+    const int q = (int)(t % NB_Q);
+    const bool live = p < n;
+    if (!live) p = n - 1;  // keep the lane group complete for the shuffles
     const float4 me = spt[p];
     const int wi = __float_as_int(me.w);
-    if (wi < 0) return;  // HP
+    if (wi < 0) return;  // HP (the whole lane group shares the point, so it leaves together)
     const int i = wi;
     const int my_cls = cls_of(sem[i]);
     int best = -1;
@@ -352,27 +405,39 @@ __global__ __launch_bounds__(TPB) void k_border(const float4* __restrict__ spt, 
         }
         return s;
     };
-    for_each_neighbour_cell(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount,
-                            [&](int beg, int end, int slot, bool trusted, bool same) {
+    // `best` is kept identical on all lanes of the group; candidates of a cell are tested NB_Q at a time
+    for_each_neighbour_cell_group(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount, q,
+                                  [&](int beg, int end, int slot, bool trusted, bool same) {
         const int rep = cell_rep[slot];
         if (rep == BIG) return;
         if (trusted) {
             const int s = seed_of(rep);
             if (s <= best) return;
             if (same) { best = s; return; }
-            for (int j = beg; j < end; ++j) {
-                const float4 q = spt[j];
-                if (__float_as_int(q.w) < 0 && sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) { best = s; return; }
+            for (int j0 = beg; j0 < end; j0 += NB_Q) {
+                const int j = j0 + q;
+                bool hit = false;
+                if (j < end) {
+                    const float4 c = spt[j];
+                    hit = __float_as_int(c.w) < 0 && sqdist(me.x, me.y, me.z, c.x, c.y, c.z) <= r2;
+                }
+                if (group_any(hit)) { best = s; return; }
             }
             return;
         }
-        for (int j = beg; j < end; ++j) {
-            const float4 q = spt[j];
-            const int wj = __float_as_int(q.w);
-            if (wj < 0 && sqdist(me.x, me.y, me.z, q.x, q.y, q.z) <= r2) best = max(best, seed_of(wj & 0x7fffffff));
+        for (int j0 = beg; j0 < end; j0 += NB_Q) {
+            const int j = j0 + q;
+            int cand = -1;
+            if (j < end) {
+                const float4 c = spt[j];
+                const int wj = __float_as_int(c.w);
+                if (wj < 0 && sqdist(me.x, me.y, me.z, c.x, c.y, c.z) <= r2) cand = seed_of(wj & 0x7fffffff);
+            }
+            best = max(best, group_max(cand));
         }
     });
-    lab[i] = best;
+    best = group_max(best);  // the maximum over the lanes' cells = the maximum over all cells
+    if (live && q == 0) lab[i] = best;
 }
 
 __global__ __launch_bounds__(TPB) void k_copy_i32(const int* __restrict__ src, int* __restrict__ dst, int n) {
@@ -721,19 +786,20 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
     if (rc != PBN_OK) return rc;
     hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(TPB), 0, stream, off_xyz, n, w.slot_of_pt, w.hstart, w.hcursor,
                        w.seg_of_pt, w.spt, w.sseg, w.sslot);
-    hipLaunchKernelGGL(k_count, dim3(cdiv((long long)n * CNT_Q, TPB)), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+    hipLaunchKernelGGL(k_count, dim3(cdiv((long long)n * NB_Q, TPB)), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
                        w.hstart, w.hcount, den);
     hipLaunchKernelGGL(k_tag_hp, dim3(nb), dim3(TPB), 0, stream, w.spt, n, den, min_pts, w.parent, w.lab, w.sslot, w.cell_rep);
-    hipLaunchKernelGGL(k_union, dim3(nb), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+    const dim3 nbq(cdiv((long long)n * NB_Q, TPB));
+    hipLaunchKernelGGL(k_union, nbq, dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
                        w.hstart, w.hcount, w.parent, w.cell_rep, w.sslot, 0);
     hipLaunchKernelGGL(k_compress, dim3(nb), dim3(TPB), 0, stream, w.spt, n, w.parent);
-    hipLaunchKernelGGL(k_union, dim3(nb), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+    hipLaunchKernelGGL(k_union, nbq, dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
                        w.hstart, w.hcount, w.parent, w.cell_rep, w.sslot, 1);
     hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, stream, w.spt, n, w.parent, sem, general, w.semseed, w.lab);
     hipLaunchKernelGGL(k_copy_i32, dim3(nb), dim3(TPB), 0, stream, w.lab, w.root, n);
     if (general)
         hipLaunchKernelGGL(k_hp_seed_general, dim3(nb), dim3(TPB), 0, stream, w.spt, n, sem, w.semseed, w.lab);
-    hipLaunchKernelGGL(k_border, dim3(nb), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+    hipLaunchKernelGGL(k_border, nbq, dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
                        w.hstart, w.hcount, sem, general, w.semseed, w.root, w.lab, w.cell_rep);
     hipLaunchKernelGGL(k_sizes, dim3(nb), dim3(TPB), 0, stream, w.lab, n, w.size);
     hipLaunchKernelGGL(k_keep, dim3(nb), dim3(TPB), 0, stream, w.lab, w.size, sem, n, para_f, w.keep);
