@@ -36,14 +36,23 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def build_workload(rank, copies, dtype, device):
+WORKLOADS = {
+    # C2 = BASELINE configs[1] (the metric's configuration), C4 = configs[3] (dense 1 cm stress scene)
+    "c2": dict(seed=2, room=(4.0, 3.2, 2.6), n_boxes=12, pitch=0.0225, voxel=0.02),
+    "c4": dict(seed=3, room=(6.4, 5.2, 2.7), n_boxes=14, pitch=0.0112, voxel=0.01),
+}
+
+
+def build_workload(rank, copies, dtype, device, workload="c2"):
     from pbnet_amd import synth
     from pbnet_amd.config import get_config
     from pbnet_amd.network.PBNet import PBNet
     cfg = get_config(test=True)
     torch.manual_seed(22)  # /root/reference/config/config.py:15
     model = PBNet(cfg).to(device).eval()
-    batch, teacher, info = synth.make_val_batch(seed=2 + rank, copies=copies)
+    w = dict(WORKLOADS[workload])
+    w["seed"] += rank
+    batch, teacher, info = synth.make_val_batch(copies=copies, **w)
     b = {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
     b["feat_voxel"] = b["feat_voxel"].to(dtype)
     t = {k: torch.from_numpy(v).to(device) for k, v in teacher.items()}
@@ -144,7 +153,7 @@ def pmc_traffic(args):
     passes over this same command line, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).
     Counters cannot be read from inside the process, so the number is only reported for the configuration it was
     collected on (default workload, bf16, 1 copy); anything else -> null."""
-    if args.copies != 1 or args.dtype != "bf16":
+    if args.copies != 1 or args.dtype != "bf16" or args.workload != "c2":
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
@@ -184,6 +193,8 @@ def main():
     ap.add_argument("--copies", type=int, default=1, help="rotated copies per scene (reference eval uses 3: TTA)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
+                    help="c2 = BASELINE configs[1] (default, the metric); c4 = configs[3], the dense 1 cm stress scene")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,7 +211,7 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
-    cfg, model, b, t, info, raw = build_workload(rank, args.copies, dtype, device)
+    cfg, model, b, t, info, raw = build_workload(rank, args.copies, dtype, device, args.workload)
 
     def barrier():
         torch.cuda.synchronize()
@@ -259,9 +270,11 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic room scene (pbnet_amd/synth.py), random-init weights (seed 22), teacher-forced "
                     "semantic/offset head outputs",
-            "config": {"workload": "configs[1]: 1 scene, %d pts, %d voxels @2cm, %d rotated cop%s, full "
+            "config": {"workload": "%s: 1 scene, %d pts, %d voxels @%gcm, %d rotated cop%s, full "
                                    "PBNet.forward (MinkUNet34C + grouping + MinkUNet14A mask + MinkUNet34C score)"
-                                   % (info["n_points"] // args.copies, info["n_voxels"] // args.copies, args.copies,
+                                   % ("configs[1]" if args.workload == "c2" else "configs[3]",
+                                      info["n_points"] // args.copies, info["n_voxels"] // args.copies,
+                                      WORKLOADS[args.workload]["voxel"] * 100, args.copies,
                                       "y" if args.copies == 1 else "ies"),
                        "points_per_step": info["n_points"], "voxels_per_step": info["n_voxels"],
                        "proposals_per_step": n_prop, "parallelism": "1 scene per GPU, no data-path collective"},

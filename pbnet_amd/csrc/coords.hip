@@ -411,19 +411,22 @@ __global__ __launch_bounds__(TPB) void k_kernel_map_cube(const int* __restrict__
                                                         int ksize, int stride, int x_fastest,
                                                         const unsigned long long* __restrict__ keys,
                                                         const int* __restrict__ vals, unsigned mask, int* __restrict__ nbr) {
+    // grid-stride over the REAL row count: the launch only knows an upper bound (the input size), and the coarse levels
+    // hold a few hundred rows of it
     const int K = ksize * ksize * ksize;
-    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
     const int n = real_n(n_dev, n_max);
-    if (e >= (long long)n * K) return;
-    const int row = (int)(e / K), k = (int)(e % K);
+    const long long total = (long long)n * K;
     const int c0 = (ksize & 1) ? ksize / 2 : 0;  // odd kernels are centred, even ones are not
-    int a = k % ksize - c0, b = (k / ksize) % ksize - c0, c = k / (ksize * ksize) - c0;
-    const int dx = (x_fastest ? a : c) * stride, dy = b * stride, dz = (x_fastest ? c : a) * stride;
-    const int4 cc = reinterpret_cast<const int4*>(out_coords)[row];
-    const int x = cc.y + dx, y = cc.z + dy, z = cc.w + dz;
-    int r = -1;
-    if (in_range(cc.x, x, y, z)) r = table_find(keys, vals, mask, pack4(cc.x, x, y, z));
-    nbr[e] = r;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+        const int row = (int)(e / K), k = (int)(e % K);
+        int a = k % ksize - c0, b = (k / ksize) % ksize - c0, c = k / (ksize * ksize) - c0;
+        const int dx = (x_fastest ? a : c) * stride, dy = b * stride, dz = (x_fastest ? c : a) * stride;
+        const int4 cc = reinterpret_cast<const int4*>(out_coords)[row];
+        const int x = cc.y + dx, y = cc.z + dy, z = cc.w + dz;
+        int r = -1;
+        if (in_range(cc.x, x, y, z)) r = table_find(keys, vals, mask, pack4(cc.x, x, y, z));
+        nbr[e] = r;
+    }
 }
 }  // namespace
 }  // namespace pbn
@@ -437,7 +440,8 @@ extern "C" int pbn_kernel_map_cube(const int32_t* out_coords, const int32_t* n_o
     if (n_out_max == 0) return PBN_OK;
     if (!out_coords || !table_keys || !table_vals || !nbr) return PBN_ERR_ARG;
     const long long total = (long long)n_out_max * kernel_size * kernel_size * kernel_size;
-    hipLaunchKernelGGL(k_kernel_map_cube, dim3(cdiv(total, TPB)), dim3(TPB), 0, stream, out_coords, n_out_dev, n_out_max,
+    const long long blocks = cdiv(total, TPB);
+    hipLaunchKernelGGL(k_kernel_map_cube, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(TPB), 0, stream, out_coords, n_out_dev, n_out_max,
                        kernel_size, tensor_stride, x_fastest, (const unsigned long long*)table_keys, table_vals,
                        (unsigned)capacity - 1, nbr);
     PBN_LAUNCH_CHECK();
