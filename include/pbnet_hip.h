@@ -238,6 +238,30 @@ int pbn_proposal_rows(const void* mask_score, int ld, float thd, const int64_t* 
                       void* proposals_ms, int32_t* coords, void* feat_out, pbn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Evaluation-time post-processing (csrc/post.hip) -- eval_map.py:55-123, the step right after PBNet.forward
+ * (SURVEY.md 8f rank 1).  A proposal is a bitset over the n_fold = N/3 folded points (pbn_post_words(n_fold) 32-bit
+ * words per row) instead of the reference's dense [P, N/3] int mask; all results are integers or fp32 quotients of
+ * exact integers, i.e. identical to the reference's tensors.
+ *   pbn_proposal_bitmask  : eval_map.py:67-70 (TTA fold `% (point_num/3)`, mask rows) + row sizes (:80)
+ *   pbn_mask_iou          : eval_map.py:90-96 for the rows listed in `rows` (NULL = all): iou f32[n_rows, n_rows]
+ *   pbn_superpoint_refine : eval_map.py:104-116 + tools/getins.py:72-98: per-point label of the picked clusters (the
+ *                           last one containing the point), per-superpoint label histogram hist[n_sp, n_pick+1] (bucket
+ *                           n_pick = unlabelled), first arg-max label per superpoint, refined per-point labels and the
+ *                           rebuilt cluster bitsets masks_out[n_pick, words] with their sizes (0 = cluster vanished)
+ *   pbn_bitmask_to_dense  : int32[n_rows, n_fold] 0/1 tensor of selected rows (the reference's `clusters`)
+ * The greedy NMS between the two (tools/mIOU.py:77-87) runs on the host on a [P, P] matrix, as in the reference. */
+int pbn_post_words(int n_fold);
+int pbn_proposal_bitmask(const int64_t* proposals_idx, int n_entries, int n_fold, int n_prop, uint32_t* masks,
+                         int32_t* counts, pbn_stream_t stream);
+int pbn_mask_iou(const uint32_t* masks, const int32_t* rows, int n_rows, int n_fold, const int32_t* counts, float* iou,
+                 pbn_stream_t stream);
+int pbn_superpoint_refine(const uint32_t* masks, const int32_t* pick, int n_pick, int n_fold, const int64_t* superpoint,
+                          int n_sp, int64_t* seg, int32_t* hist, int64_t* sp_label, int64_t* seg_refined,
+                          uint32_t* masks_out, int32_t* counts_out, pbn_stream_t stream);
+int pbn_bitmask_to_dense(const uint32_t* masks, const int32_t* rows, int n_rows, int n_fold, int32_t* dense,
+                         pbn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * One-call sub-pipelines (csrc/executor.hip): they only sequence the entry points above.
  *
  * pbn_coords_build: everything a MinkUNet needs from one coordinate lineage -- de-duplication, the four coarser

@@ -87,6 +87,12 @@ SIGNATURES = {
     "pbn_mask_count": (c_int, [c_vp, c_int, c_float, c_vp, c_int, c_int, c_int, c_i32p, c_i32p, c_vp]),
     "pbn_proposal_rows": (c_int, [c_vp, c_int, c_float, c_vp, c_vp, c_int, c_i32p, c_i32p, c_f32p, c_float, c_float, c_vp,
                                   c_int, c_int, c_int, c_vp, c_vp, c_i32p, c_vp, c_vp]),
+    "pbn_post_words": (c_int, [c_int]),
+    "pbn_proposal_bitmask": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_i32p, c_vp]),
+    "pbn_mask_iou": (c_int, [c_vp, c_i32p, c_int, c_int, c_i32p, c_f32p, c_vp]),
+    "pbn_superpoint_refine": (c_int, [c_vp, c_i32p, c_int, c_int, c_vp, c_int, c_vp, c_i32p, c_vp, c_vp, c_vp, c_i32p,
+                                      c_vp]),
+    "pbn_bitmask_to_dense": (c_int, [c_vp, c_i32p, c_int, c_int, c_i32p, c_vp]),
     "pbn_kernel_map_cube": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_coords_arena_bytes": (c_size, [c_int, c_int, ctypes.POINTER(CoordsLayout)]),
     "pbn_coords_build": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(CoordsLayout), c_vp]),
