@@ -123,3 +123,20 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def segmented_scores_golden():
+    """tools/mIOU.py:34-49 (used by model_fn, network/PBNet.py:412): outputs of the reference function itself."""
+    from tools.mIOU import get_segmented_scores
+    rng = np.random.default_rng(7)
+    s = rng.random(4096).astype(np.float32)
+    s[:6] = [0.0, 0.25, 0.75, 1.0, 0.2499999, 0.7500001]
+    out = {}
+    for fg, bg in ((0.75, 0.25), (1.0, 0.0), (0.5, 0.2)):
+        out["fg%g_bg%g" % (fg, bg)] = get_segmented_scores(torch.from_numpy(s), fg, bg).numpy()
+    np.savez_compressed(os.path.join(HERE, "segmented_scores.npz"), scores=s, **out)
+    print("segmented_scores: %d thresholds" % len(out))
+
+
+if __name__ == "__main__":
+    segmented_scores_golden()

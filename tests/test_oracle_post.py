@@ -30,3 +30,16 @@ def test_oracle_matches_reference_outputs(path):
     assert np.array_equal(out["clusters"], g["out_clusters"])
     assert np.array_equal(out["cluster_scores"], g["out_cluster_scores"])
     assert np.array_equal(out["cluster_semantic_id"], g["out_cluster_semantic_id"])
+
+
+def test_get_segmented_scores_matches_reference_function():
+    """network/PBNet.py:412 -> tools/mIOU.py:34-49; golden = outputs of the reference function (make_post_golden.py)."""
+    import torch
+    from pbnet_amd.network.PBNet import get_segmented_scores
+    g = np.load(os.path.join(HERE, "golden", "segmented_scores.npz"))
+    s = torch.from_numpy(g["scores"])
+    for key in g.files:
+        if key == "scores":
+            continue
+        fg, bg = (float(v[2:]) for v in key.split("_"))
+        assert np.array_equal(get_segmented_scores(s, fg, bg).numpy(), g[key]), key
