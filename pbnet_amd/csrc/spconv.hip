@@ -6,14 +6,16 @@
 // One kernel serves k=5 / k=3 / k=2,s=2 down / k=2,s=2 transposed / 1x1 / linear: they differ only in the table.
 //
 // Mapping (MI355X-first, not a translation of gather-GEMM-scatter):
-//   * workgroup = 4 waves = TM output rows (TM = 64 or 128) x NT*16 output channels; accumulators stay in registers
-//     for the whole K*Cin reduction, so there is no scatter, no atomics and a fixed summation order (deterministic);
+//   * workgroup = 4 waves x NF 16-row fragments = TM output rows (128 in production) x NT*16 output channels;
+//     accumulators stay in registers for the whole K*Cin reduction, so there is no scatter, no atomics and a fixed
+//     summation order (deterministic);
 //   * the reduction axis is the flattened (kernel offset, input channel) axis cut into STEPS of 4 x 16-byte vectors;
 //     each lane gathers its MFMA operand (16 B of one neighbour row) straight from the feature slab in HBM/L2 --
 //     rows are contiguous, a 16-lane group reads whole 64-B row segments;
-//   * the rulebook tile nbr[TM][K] is staged once in LDS; steps whose offsets have no neighbour in the tile are
-//     dropped from the step list (sparse scenes: ~7 of 27 offsets populated);
-//   * weights are pre-packed in MFMA-fragment order, double-buffered through LDS and shared by the 4 waves;
+//   * the rulebook tile nbr[TM][K] is staged once in LDS; offsets without a neighbour in the tile are dropped from the
+//     tile's group list, waves whose fragments are empty for an offset skip its MFMAs;
+//   * weights are pre-packed in MFMA-fragment order and reach LDS through the LDS-DMA path (two ring slots, shared by
+//     the 4 waves); the main loop is described at k_spconv below;
 //   * the products are computed transposed (D = W^T-tile x X^T-tile) so that each lane ends up with 4 CONSECUTIVE
 //     output channels of one row: the epilogue (folded BN scale/shift, bias, residual, ReLU, down-cast) is applied
 //     in registers and written with 8/16-byte stores;
