@@ -14,7 +14,9 @@ def _cap_host_threads():
     try:
         import torch
         from .hostinfo import usable_cores
-        budget = max(1, min(usable_cores(), 16))
+        # one process per GPU: the ranks of a node share the budget (torchrun exports LOCAL_WORLD_SIZE)
+        ranks = max(1, int(_os.environ.get("LOCAL_WORLD_SIZE", _os.environ.get("WORLD_SIZE", "1")) or 1))
+        budget = max(1, min(usable_cores() // ranks, 16))
         if torch.get_num_threads() > budget:
             torch.set_num_threads(budget)
     except Exception:  # never make the import fail on an exotic host
