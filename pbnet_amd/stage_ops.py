@@ -158,6 +158,8 @@ def proposal_rows(mask_score, thd, row_scene, point_idx, dense_of, block_cnt, to
         assert point_feat.stride(1) == 1 and point_feat.dtype == ms.dtype
         c, ld_feat = int(point_feat.shape[1]), point_feat.stride(0)
         feat = torch.empty(total, c, dtype=point_feat.dtype, device=dev)
+    if total == 0:               # no row passed the threshold: nothing to launch (empty tensors have no address)
+        return prop_idx, prop_ms, coords, feat
     vp = N.c_vp
     rc = N.lib().pbn_proposal_rows(
         vp(ms.data_ptr()), ms.stride(0), float(thd), N.ptr(row_scene), N.ptr(point_idx), n, N.ptr(dense_of),

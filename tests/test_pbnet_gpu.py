@@ -107,3 +107,31 @@ def test_forward_and_model_fn_eval(setup):
         r = model(batch["feat_voxel"], batch["xyz_voxel"], batch["xyz_original"], batch["v2p_index"], None, 1, "test")
     model.cluster_epoch = cfg.cluster_epoch
     assert "proposals" not in r
+
+
+def test_forward_degenerate_scenes(setup):
+    """The data-dependent early exits of PBNet.py:144-279 on the fused inference path: no class passes the population
+    gate; every mask score falls under the threshold (no proposal survives); both must return well-formed empties."""
+    cfg, model, sd, batch, teacher = setup
+    args = (batch["feat_voxel"], batch["xyz_voxel"], batch["xyz_original"], batch["v2p_index"], None, 1, "test")
+    # (a) every point predicted as floor (class 0): nothing to group
+    t0 = {"sem_score": torch.full_like(teacher["sem_score"], -5.0), "offset": teacher["offset"]}
+    t0["sem_score"][:, 0] = 5.0
+    with torch.no_grad():
+        ret = model(*args, teacher=t0)
+    assert ret["proposals"][0].shape == (0, 2) and ret["proposals"][1].shape[0] == 1 and ret["clt_scores"].numel() == 0
+    assert torch.equal(ret["sem_pred_p"].cpu(), torch.zeros(batch["xyz_original"].shape[0], dtype=torch.int64))
+    # (b) the mask head answers 0 everywhere: every local scene dies at the threshold
+    bias = model.linear_binary[3].linear.bias
+    keep = bias.detach().clone()
+    try:
+        with torch.no_grad():
+            bias.fill_(-60.0)
+            ret = model(*args, teacher=teacher)
+        assert ret["proposals"][0].shape[0] == 0 and ret["proposals"][1].tolist() == [0] and ret["clt_scores"].numel() == 0
+    finally:
+        with torch.no_grad():
+            bias.copy_(keep)
+    with torch.no_grad():                                      # and the model is intact afterwards
+        ret = model(*args, teacher=teacher)
+    assert ret["proposals"][1].shape[0] > 1
