@@ -197,6 +197,12 @@ int pbn_local_scene_rows(const int32_t* ent_row_start, const int32_t* ent_member
 int pbn_gather_pad_rows(const void* in, int ld_in_bytes, int row_bytes, const int64_t* idx, int n, void* out,
                         int ld_out_bytes, pbn_stream_t stream);
 
+/* pbn_gather_rulebook_rows -- the gathered operand of the weight gradient (training, BASELINE configs[2]):
+ * out[v, j, 0:row_bytes] = in[nbr[v, k0 + j], 0:row_bytes] for j < kc, zeros where nbr is -1; out is dense
+ * [n, kc, row_bytes].  dW[k0:k0+kc] is then one dense contraction of this slab with the output gradient. */
+int pbn_gather_rulebook_rows(const void* in, int ld_in_bytes, int row_bytes, const int32_t* nbr, int n_offsets, int k0,
+                             int kc, int n, void* out, pbn_stream_t stream);
+
 /* pbn_mlp_rows -- the two-layer heads of network/PBNet.py:43-82 in eval mode, one launch per head:
  *   out[i, 0:n_out] = act( W2 . prelu( (W1 . x) * scale + shift ) + b2 ),   x = in[row(i), 0:channels],
  *   row(i) = idx_b[idx_a[i]] (either index level may be NULL), act = sigmoid or identity.

@@ -133,10 +133,19 @@ def _wgrad(feats, grad_out, nbr, cin, cout):
     f = feats[:, :cin]
     g = grad_out[:, :cout].contiguous()
     kc = max(1, min(k, WGRAD_CHUNK_BYTES // max(1, v * cin * f.element_size())))
+    es = f.element_size()
+    native = f.stride(1) == 1 and (cin * es) % 4 == 0 and (f.stride(0) * es) % 4 == 0 and nbr.is_contiguous()
     for k0 in range(0, k, kc):
-        idx = nbr[:, k0:k0 + kc].long()                                       # [V, kc]
-        a = f[idx.clamp(min=0)] * (idx >= 0).unsqueeze(-1).to(f.dtype)         # [V, kc, Cin], zeros where no neighbour
-        dw[k0:k0 + kc] = (a.reshape(v, -1).t() @ g).float().view(-1, cin, cout)
+        kk = min(kc, k - k0)
+        if native:     # one launch: rows gathered through the rulebook columns, zeros where there is no neighbour
+            a = torch.empty(v, kk * cin, dtype=f.dtype, device=f.device)
+            N.check(N.lib().pbn_gather_rulebook_rows(N.c_vp(f.data_ptr()), f.stride(0) * es, cin * es, N.ptr(nbr), k, k0, kk,
+                                                     v, N.c_vp(a.data_ptr()), N.current_stream()),
+                    "pbn_gather_rulebook_rows")
+        else:
+            idx = nbr[:, k0:k0 + kk].long()                                    # [V, kc]
+            a = (f[idx.clamp(min=0)] * (idx >= 0).unsqueeze(-1).to(f.dtype)).reshape(v, -1)
+        dw[k0:k0 + kk] = (a.t() @ g).float().view(-1, cin, cout)
     return dw
 
 

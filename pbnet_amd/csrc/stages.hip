@@ -375,6 +375,21 @@ __global__ __launch_bounds__(TPB) void k_proposal_rows(const T* __restrict__ sco
     }
 }
 
+
+// ---- wgrad operand: out[v, j, :] = in[nbr[v, k0 + j], :] (zeros where there is no neighbour), 32-bit words ----------
+__global__ __launch_bounds__(TPB) void k_gather_rulebook_rows(const unsigned* __restrict__ in, int ld_in_w, int row_w,
+                                                             const int* __restrict__ nbr, int K, int k0, int kc, int n,
+                                                             unsigned* __restrict__ out) {
+    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+    const long long per_row = (long long)kc * row_w;
+    if (e >= (long long)n * per_row) return;
+    const int v = (int)(e / per_row);
+    const int r = (int)(e - (long long)v * per_row);
+    const int j = r / row_w, w = r - j * row_w;
+    const int src = nbr[(size_t)v * K + k0 + j];
+    out[e] = src >= 0 ? in[(size_t)src * ld_in_w + w] : 0u;
+}
+
 }  // namespace
 }  // namespace pbn
 
@@ -558,6 +573,21 @@ extern "C" int pbn_proposal_rows(const void* mask_score, int ld, float thd, cons
     else if (dtype == PBN_F16) PBN_PR(__half);
     else return PBN_ERR_ARG;
 #undef PBN_PR
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_gather_rulebook_rows(const void* in, int ld_in_bytes, int row_bytes, const int32_t* nbr, int n_offsets,
+                                        int k0, int kc, int n, void* out, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || row_bytes <= 0 || (row_bytes & 3) || (ld_in_bytes & 3) || ld_in_bytes < row_bytes || k0 < 0 || kc < 1 ||
+        k0 + kc > n_offsets)
+        return PBN_ERR_ARG;
+    if (n == 0) return PBN_OK;
+    if (!in || !nbr || !out || (((uintptr_t)in | (uintptr_t)out) & 3)) return PBN_ERR_ARG;
+    const long long total = (long long)n * kc * (row_bytes / 4);
+    hipLaunchKernelGGL(k_gather_rulebook_rows, dim3(cdiv(total, TPB)), dim3(TPB), 0, stream, (const unsigned*)in,
+                       ld_in_bytes / 4, row_bytes / 4, nbr, n_offsets, k0, kc, n, (unsigned*)out);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
