@@ -197,6 +197,14 @@ int pbn_local_scene_rows(const int32_t* ent_row_start, const int32_t* ent_member
 int pbn_gather_pad_rows(const void* in, int ld_in_bytes, int row_bytes, const int64_t* idx, int n, void* out,
                         int ld_out_bytes, pbn_stream_t stream);
 
+/* pbn_pack_weight -- fp32 master weights [n_offsets, dim_a, dim_b] (the reference's `kernel` layout [K, Cin, Cout]) into
+ * the `w_packed` fragment order pbn_spconv_forward reads, in one launch.  flip mirrors the offsets (K-1-k), transpose
+ * swaps the channel roles: flip + transpose of a centred forward kernel are its input-gradient weights.
+ * vecs_per_offset / n_steps / cout_padded as for pbn_spconv_forward with (Cin, Cout) = transpose ? (dim_b, dim_a) :
+ * (dim_a, dim_b).  out: n_steps * cout_padded/16 * 1024 bytes. */
+int pbn_pack_weight(const float* src, int n_offsets, int dim_a, int dim_b, int flip, int transpose, int dtype,
+                    int vecs_per_offset, int n_steps, int cout_padded, void* out, pbn_stream_t stream);
+
 /* pbn_gather_rulebook_rows -- the gathered operand of the weight gradient (training, BASELINE configs[2]):
  * out[v, j, 0:row_bytes] = in[nbr[v, k0 + j], 0:row_bytes] for j < kc, zeros where nbr is -1; out is dense
  * [n, kc, row_bytes].  dW[k0:k0+kc] is then one dense contraction of this slab with the output gradient. */

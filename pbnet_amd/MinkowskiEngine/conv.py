@@ -22,17 +22,33 @@ def _vpo(cin, dtype):
     return v if v in (1, 2) else (v + 3) // 4 * 4
 
 
-def pack_weight(kernel, dtype):
-    """kernel [K, Cin, Cout] (fp32 master) -> MFMA-fragment order [n_steps, cout_p/16, 64, 16 bytes] of `dtype`.
+def pack_weight(kernel, dtype, flip=False, transpose=False):
+    """kernel [K, A, B] (fp32 master) -> MFMA-fragment order [n_steps, cout_p/16, 64, 16 bytes] of `dtype`, where the
+    convolution's (Cin, Cout) = (B, A) if transpose else (A, B) and flip mirrors the offsets (flip + transpose of a
+    centred kernel = its input-gradient weights).  One native launch on the device (pbn_pack_weight).
 
     Layout contract: include/pbnet_hip.h (pbn_spconv_forward, `w_packed`)."""
-    k, cin, cout = kernel.shape
+    k = kernel.shape[0]
+    cin, cout = (kernel.shape[2], kernel.shape[1]) if transpose else (kernel.shape[1], kernel.shape[2])
     e = _ELEMS[dtype]
     vpo = _vpo(cin, dtype)
     cin_p = vpo * e
     cout_p = (cout + 15) // 16 * 16
     n_steps = (k * vpo + 3) // 4
     chunk = 4 * e
+    if kernel.is_cuda:
+        src = kernel.detach()
+        if src.dtype != torch.float32 or not src.is_contiguous():
+            src = src.float().contiguous()
+        w = torch.empty(n_steps, cout_p // 16, 64, e, dtype=dtype, device=kernel.device)
+        N.check(N.lib().pbn_pack_weight(N.ptr(src), int(k), int(kernel.shape[1]), int(kernel.shape[2]), int(flip),
+                                        int(transpose), _DT[dtype], vpo, n_steps, cout_p, N.c_vp(w.data_ptr()),
+                                        N.current_stream()), "pbn_pack_weight")
+        return w, vpo, n_steps, cout_p
+    if flip:
+        kernel = kernel.flip(0)
+    if transpose:
+        kernel = kernel.transpose(1, 2)
     w = torch.zeros(n_steps * chunk, cout_p, dtype=torch.float32, device=kernel.device)
     wp = torch.zeros(k, cin_p, cout_p, dtype=torch.float32, device=kernel.device)
     wp[:, :cin, :cout] = kernel.detach().float()
@@ -62,7 +78,7 @@ class _PackCache(object):
         key = (dtype, weight._version, weight.data_ptr(), weight.device)
         hit = self.store.get(dtype)
         if hit is None or hit[0] != key:
-            hit = (key, pack_weight(weight.detach().t().unsqueeze(0), dtype))
+            hit = (key, pack_weight(weight.detach().unsqueeze(0), dtype, transpose=True))
             self.store[dtype] = hit
         return hit[1]
 
@@ -172,8 +188,7 @@ class _ConvFn(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         grad_feats = grad_kernel = grad_bias = None
         if ctx.needs_input_grad[0]:
-            wt = k3.detach().flip(0) if ctx.flip else k3.detach()
-            packed = pack_weight(wt.transpose(1, 2).contiguous(), grad_out.dtype)   # [K, Cout, Cin]
+            packed = pack_weight(k3.detach(), grad_out.dtype, flip=bool(ctx.flip), transpose=True)   # [K, Cout, Cin]
             gi = spconv_forward(grad_out, ctx.dgrad_nbr, feats.shape[0], packed)
             grad_feats = gi if gi.shape[1] == feats.shape[1] else gi[:, :feats.shape[1]]
         if ctx.needs_input_grad[1]:

@@ -94,6 +94,7 @@ SIGNATURES = {
                                       c_vp]),
     "pbn_bitmask_to_dense": (c_int, [c_vp, c_i32p, c_int, c_int, c_i32p, c_vp]),
     "pbn_gather_rulebook_rows": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "pbn_pack_weight": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "pbn_kernel_map_cube": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_coords_arena_bytes": (c_size, [c_int, c_int, ctypes.POINTER(CoordsLayout)]),
     "pbn_coords_build": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(CoordsLayout), c_vp]),

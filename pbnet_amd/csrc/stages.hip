@@ -390,6 +390,35 @@ __global__ __launch_bounds__(TPB) void k_gather_rulebook_rows(const unsigned* __
     out[e] = src >= 0 ? in[(size_t)src * ld_in_w + w] : 0u;
 }
 
+
+// ---- weight packing: fp32 master [K, A, B] -> MFMA-fragment order (include/pbnet_hip.h, pbn_spconv_forward) ----------
+// element (k, ci, co) of the convolution = src[flip ? K-1-k : k][ci][co], or [..][co][ci] when `transpose` (the dgrad
+// weights of a forward kernel).  One thread per packed element; E = elements per 16-byte vector.
+template <typename T>
+__global__ __launch_bounds__(TPB) void k_pack_weight(const float* __restrict__ src, int K, int A, int B, int flip,
+                                                    int transpose, int cin, int cout, int cin_p, int cout_p, int n_steps,
+                                                    T* __restrict__ out) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+    const int ntt = cout_p / 16;
+    const long long total = (long long)n_steps * ntt * 64 * E;
+    if (e >= total) return;
+    const int j = (int)(e % E);
+    const int lane = (int)((e / E) % 64);
+    const int tt = (int)((e / (E * 64)) % ntt);
+    const int st = (int)(e / ((long long)E * 64 * ntt));
+    const int g = lane >> 4, c = lane & 15;
+    const int r = st * 4 * E + g * E + j;           // row of the flattened (offset, channel) axis
+    const int k = r / cin_p, ci = r - k * cin_p;
+    const int co = tt * 16 + c;
+    float v = 0.f;
+    if (k < K && ci < cin && co < cout) {
+        const int ks = flip ? K - 1 - k : k;
+        v = transpose ? src[((size_t)ks * A + co) * B + ci] : src[((size_t)ks * A + ci) * B + co];
+    }
+    RowIO<T>::store(out + e, v);
+}
+
 }  // namespace
 }  // namespace pbn
 
@@ -588,6 +617,34 @@ extern "C" int pbn_gather_rulebook_rows(const void* in, int ld_in_bytes, int row
     const long long total = (long long)n * kc * (row_bytes / 4);
     hipLaunchKernelGGL(k_gather_rulebook_rows, dim3(cdiv(total, TPB)), dim3(TPB), 0, stream, (const unsigned*)in,
                        ld_in_bytes / 4, row_bytes / 4, nbr, n_offsets, k0, kc, n, (unsigned*)out);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_pack_weight(const float* src, int n_offsets, int dim_a, int dim_b, int flip, int transpose, int dtype,
+                               int vecs_per_offset, int n_steps, int cout_padded, void* out, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!src || !out || n_offsets < 1 || dim_a < 1 || dim_b < 1 || vecs_per_offset < 1 || n_steps < 1 || cout_padded < 16 ||
+        (cout_padded & 15))
+        return PBN_ERR_ARG;
+    const int esz = dtype == PBN_F32 ? 4 : 2;
+    const int e = 16 / esz;
+    const int cin = transpose ? dim_b : dim_a, cout = transpose ? dim_a : dim_b;
+    const int cin_p = vecs_per_offset * e;
+    if (cin_p < cin || cout_padded < cout || (long long)n_steps * 4 * e < (long long)n_offsets * cin_p) return PBN_ERR_ARG;
+    const long long total = (long long)n_steps * (cout_padded / 16) * 64 * e;
+    const dim3 grid(cdiv(total, TPB));
+    if (dtype == PBN_F32)
+        hipLaunchKernelGGL(k_pack_weight<float>, grid, dim3(TPB), 0, stream, src, n_offsets, dim_a, dim_b, flip, transpose, cin,
+                           cout, cin_p, cout_padded, n_steps, (float*)out);
+    else if (dtype == PBN_BF16)
+        hipLaunchKernelGGL(k_pack_weight<__hip_bfloat16>, grid, dim3(TPB), 0, stream, src, n_offsets, dim_a, dim_b, flip,
+                           transpose, cin, cout, cin_p, cout_padded, n_steps, (__hip_bfloat16*)out);
+    else if (dtype == PBN_F16)
+        hipLaunchKernelGGL(k_pack_weight<__half>, grid, dim3(TPB), 0, stream, src, n_offsets, dim_a, dim_b, flip, transpose,
+                           cin, cout, cin_p, cout_padded, n_steps, (__half*)out);
+    else
+        return PBN_ERR_ARG;
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
