@@ -80,6 +80,22 @@ def test_duplicate_coordinates_first_occurrence():
     bad = torch.tensor([[0, 0, 0, 0], [0, 40000, 0, 0]], dtype=torch.int32)
     with pytest.raises(ValueError):
         ME.SparseTensor(torch.zeros(2, 4), bad, device=DEV)
+    # the inference constructor (one native call: de-duplication + Z-order + pyramid, pbn_coords_prepare) must agree
+    with torch.no_grad():
+        st3 = ME.SparseTensor(feats, torch.from_numpy(coords), device=DEV)
+        assert st3.coordinate_manager._native is not None
+        assert np.array_equal(st3.C.cpu().numpy(), c_ref)
+        assert torch.equal(st3.F.cpu(), f_ref)
+        assert torch.equal(st3.inverse_mapping.cpu(), inv_ref)
+        sv = st3.coordinate_manager.sorted()
+        assert torch.equal(sv.inv_perm[sv.perm].cpu(), torch.arange(len(c_ref)))
+        assert np.array_equal(sv.pyramid.coordinates(1).cpu().numpy(), c_ref[sv.perm.cpu().numpy()])
+        for s_ in (2, 4, 8, 16):      # coarser levels hold the same voxel sets as the external-order pyramid
+            a = {tuple(r) for r in sv.pyramid.coordinates(s_).cpu().numpy().tolist()}
+            b = {tuple(r) for r in st.coordinate_manager.coordinates(s_).cpu().numpy().tolist()}
+            assert a == b
+        with pytest.raises(ValueError):
+            ME.SparseTensor(torch.zeros(2, 4), bad, device=DEV)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL), (torch.bfloat16, 6e-2), (torch.float16, 1e-2)])
