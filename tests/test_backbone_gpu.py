@@ -281,3 +281,23 @@ def test_full_size_scene_linearity_and_determinism():
         valid = nb[:, k] >= 0
         ref[valid] += a[nb[valid, k]].double() @ conv.kernel[k].double()
     assert (ya[rows].double() - ref).abs().max().item() < 1e-4
+
+
+def test_loader_voxelize_batch_matches_per_scene_quantize_and_collate():
+    """dataset_preprocess.py:345-375 ('Voxel and Batch' of valMerge): one batched device de-duplication == per-scene
+    sparse_quantize + v2p offsets + sparse_collate (oracle restatement of the ME rules, fixture B5)."""
+    from pbnet_amd import loader_ops
+    rng = np.random.default_rng(11)
+    xyz_list = [rng.uniform(-1, 3, (n, 3)) for n in (4000, 2500, 3300)]
+    feat_list = [rng.normal(size=(len(x), 6)).astype(np.float32) for x in xyz_list]
+    xv, fv, v2p = loader_ops.voxelize_batch(xyz_list, feat_list, 0.02, device=DEV)
+    want_c, want_f, want_v2p, total = [], [], [], 0
+    for b, (x, f) in enumerate(zip(xyz_list, feat_list)):
+        qc, qf, idx, inv = R.sparse_quantize(x, f, 0.02)
+        want_c.append(np.concatenate([np.full((len(qc), 1), b, np.int32), qc.astype(np.int32)], 1))
+        want_f.append(qf)
+        want_v2p.append(inv + total)
+        total += len(qc)
+    assert np.array_equal(xv.cpu().numpy(), np.concatenate(want_c))
+    assert np.array_equal(fv.cpu().numpy(), np.concatenate(want_f))
+    assert np.array_equal(v2p.cpu().numpy(), np.concatenate(want_v2p))
