@@ -1,6 +1,6 @@
 """Post-processing (eval_map.py:55-123) on the 3-copy bench scene's own proposals: device path vs the numpy oracle."""
 import sys, os, time, types
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import numpy as np, torch
 import bench
 from pbnet_amd import postprocess as PP
