@@ -276,6 +276,22 @@ int pbn_bitmask_to_dense(const uint32_t* masks, const int32_t* rows, int n_rows,
                          pbn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * ScanNet AP evaluator, the association step of /root/reference/tools/eval.py:205-250
+ * (`assign_instances_for_scan`).  The reference counts, for every (prediction, ground-truth instance) pair, the points
+ * both contain with one pass over the scene per pair (:239) plus one for the void overlap (:235); here ONE pass per
+ * prediction fills a row of the overlap table: inter[p][gt_index[i]] += 1 for every point i with masks[p][i] != 0.
+ *   masks    : int32[n_pred, n_pts], any non-zero value = inside (eval.py:226 `np.not_equal(pred_mask, 0)`)
+ *   gt_index : int32[n_pts], the point's ground-truth id as an index into the scene's sorted unique id list
+ *              (0 <= index < n_gt; the ids themselves -- class*1000+instance+1, 0 = unannotated,
+ *              datasets/scannetv2/get_val_gt.py:26-39 -- stay on the host)
+ *   inter    : int32[n_pred, n_gt] out (zeroed here).  Row sums are the predictions' vertex counts (:227), columns of
+ *              non-benchmark ids sum to the void intersection (:235), the rest are the `intersection` fields (:239).
+ * Matching and the precision/recall integration (eval.py:27-190) are scalar bookkeeping on these counts and run on
+ * the host (pbnet_amd/evaluate.py). */
+int pbn_instance_overlap(const int32_t* masks, int n_pred, int n_pts, const int32_t* gt_index, int n_gt, int32_t* inter,
+                         pbn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * One-call sub-pipelines (csrc/executor.hip): they only sequence the entry points above.
  *
  * pbn_coords_build: everything a MinkUNet needs from one coordinate lineage -- de-duplication, the four coarser

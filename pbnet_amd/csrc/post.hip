@@ -105,6 +105,56 @@ __global__ __launch_bounds__(TPB) void k_bits_to_dense(const unsigned* __restric
     dense[e] = (masks[(size_t)src * words + (pt >> 5)] >> (pt & 31)) & 1u;
 }
 
+// inter[p][gt_index[i]] += 1 for every point i inside prediction p (mask value != 0): the association counts of
+// tools/eval.py:230-245 (`count_nonzero(logical_and(gt_ids == id, pred_mask))` per (prediction, instance) pair, one pass
+// over the scene per pair in the reference) as ONE pass per prediction.  A block owns OVERLAP_CHUNK consecutive points of
+// one prediction; instances are runs of neighbouring vertices, so a wave first merges lanes that hit the same bin
+// (leader adds the lane count) before touching the LDS histogram.
+constexpr int OVERLAP_CHUNK = 4096;
+constexpr int OVERLAP_LDS_BINS = 8192;
+
+__global__ __launch_bounds__(TPB) void k_instance_overlap(const int* __restrict__ masks, int n_pts,
+                                                         const int* __restrict__ gt_index, int n_gt, int use_lds,
+                                                         int* __restrict__ inter) {
+    __shared__ int s_hist[OVERLAP_LDS_BINS];
+    const int p = blockIdx.y;
+    const int lo = blockIdx.x * OVERLAP_CHUNK;
+    const int hi = min(n_pts, lo + OVERLAP_CHUNK);
+    int* out = inter + (size_t)p * n_gt;
+    if (use_lds) {
+        for (int b = threadIdx.x; b < n_gt; b += TPB) s_hist[b] = 0;
+        __syncthreads();
+    }
+    const int* row = masks + (size_t)p * n_pts;
+    for (int base = lo; base < hi; base += TPB) {         // uniform trip count: the ballots below need whole waves
+        const int i = base + threadIdx.x;
+        int bin = -1;
+        if (i < hi && row[i] != 0) {
+            const int g = gt_index[i];
+            if (g >= 0 && g < n_gt) bin = g;
+        }
+        unsigned long long todo = __ballot(bin >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lb = __shfl(bin, leader);
+            const unsigned long long same = __ballot(bin == lb) & todo;
+            if ((int)(threadIdx.x & 63) == leader) {
+                const int c = __popcll(same);
+                if (use_lds) atomicAdd(&s_hist[lb], c);
+                else atomicAdd(&out[lb], c);
+            }
+            todo &= ~same;
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < n_gt; b += TPB) {
+            const int c = s_hist[b];
+            if (c) atomicAdd(&out[b], c);
+        }
+    }
+}
+
 }  // namespace
 }  // namespace pbn
 
@@ -170,6 +220,21 @@ extern "C" int pbn_bitmask_to_dense(const uint32_t* masks, const int32_t* rows, 
     if (!masks || !dense) return PBN_ERR_ARG;
     hipLaunchKernelGGL(k_bits_to_dense, dim3(cdiv((long long)n_rows * n_fold, TPB)), dim3(TPB), 0, stream, masks, rows, n_rows,
                        pbn_post_words(n_fold), n_fold, dense);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_instance_overlap(const int32_t* masks, int n_pred, int n_pts, const int32_t* gt_index, int n_gt,
+                                    int32_t* inter, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_pred < 0 || n_pts < 0 || n_gt < 1) return PBN_ERR_ARG;
+    if (n_pred == 0) return PBN_OK;
+    if (!inter) return PBN_ERR_ARG;
+    PBN_HIP_CHECK(hipMemsetAsync(inter, 0, sizeof(int32_t) * (size_t)n_pred * n_gt, stream));
+    if (n_pts == 0) return PBN_OK;
+    if (!masks || !gt_index) return PBN_ERR_ARG;
+    hipLaunchKernelGGL(k_instance_overlap, dim3(cdiv(n_pts, OVERLAP_CHUNK), n_pred), dim3(TPB), 0, stream, masks, n_pts,
+                       gt_index, n_gt, n_gt <= OVERLAP_LDS_BINS ? 1 : 0, inter);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
