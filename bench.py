@@ -11,12 +11,21 @@ workload: configs[1] -- one synthetic ScanNet-sized scene (seed 2: 161 517 point
 step    : one PBNet.forward over one scene per rank.  N > 1: every rank owns a different scene (seed 2 + rank), no
           data-path collective (scenes are independent at inference) -> weak scaling; the process group only carries
           the barrier and the max-over-ranks of the elapsed time.
+in flight: the K steps of a rank are taken round-robin by `--inflight` host threads (default 3), each on its own HIP
+          stream: most launches of the path are far too small for 256 CUs, so kernels of independent scenes overlap
+          on the device and one scene's host read-backs hide behind another's kernels.  Results are bit-identical to
+          the one-at-a-time loop (tests/test_pbnet_gpu.py::test_scenes_in_flight).  `ms_per_step` is elapsed / K (the
+          inverse rate); the latency of a scene alone on the GPU is config.one_scene_in_flight_ms_per_scene, and
+          `--inflight 1` runs the reference's one-scene-at-a-time loop.
 
 Also on the JSON line:
   roofline     -- the dominant kernel family (k_spconv, csrc/spconv.hip): algorithmic bytes of every launch (SURVEY.md
                   8d: (V_in*C_in + V_out*C_out)*b + K*C_in*C_out*b + 8*P) divided by that launch's duration, measured
-                  with HIP events on the launching stream in an instrumented pass over the same steps; `traffic` is the
-                  HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_summary.json).
+                  with HIP events on the launching stream in an instrumented pass over the same steps in the same
+                  in-flight mode (a launch that shares the CUs with other streams' kernels takes longer: the per-launch
+                  figure falls while the whole-job rate rises; `one_scene_in_flight` holds the same figures for
+                  launches that have the GPU to themselves); `traffic` is the HBM bytes per launch from the committed
+                  PMC passes (profiles/r01_pmc_summary.json).
   cpu_baseline -- the CPU oracle (oracle/, a restatement: the reference's own CPU path cannot be installed) timed on
                   the host cores of rank 0 at N=1 on one full scene of the same workload.
 """
@@ -24,6 +33,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -77,6 +87,7 @@ class ConvProbe(object):
         self.flops = 0
         self.launches = 0
         self.py_records = []
+        self.lock = threading.Lock()
 
     def _pairs(self, cm, kind, lin, lout, rows):
         if kind == 0:
@@ -87,6 +98,10 @@ class ConvProbe(object):
         return int((nbr >= 0).sum().item())
 
     def unet_sink(self, model, plan, rows, cm, esz, op_ms):
+        with self.lock:
+            self._unet_sink(plan, rows, cm, esz, op_ms)
+
+    def _unet_sink(self, plan, rows, cm, esz, op_ms):
         pair_cache = {}
         widths = [plan["bufs"][i].width for i in range(plan["n_bufs"])]
         for i in range(plan["n_ops"]):
@@ -188,11 +203,13 @@ def cpu_baseline(cfg, model, raw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--copies", type=int, default=1, help="rotated copies per scene (reference eval uses 3: TTA)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="scenes in flight per GPU (one host thread + HIP stream each); 1 = the reference's loop")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
                     help="c2 = BASELINE configs[1] (default, the metric); c4 = configs[3], the dense 1 cm stress scene")
     args = ap.parse_args()
@@ -219,15 +236,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ret = None
-    for _ in range(args.warmup):
-        ret = one_step(model, b, t)
+    # `--inflight M`: M host threads, each with its own HIP stream, take the K steps round-robin (scenes are independent
+    # units, eval_map.py:48-50); kernels of different scenes overlap on the device and one scene's host read-backs hide
+    # behind another's kernels.  M = 1 is the reference's one-scene-at-a-time loop.
+    streams = [torch.cuda.Stream(device) for _ in range(args.inflight)] if args.inflight > 1 else [None]
+    last = [None] * len(streams)
+
+    def run_steps(n):
+        if args.inflight == 1:
+            for _ in range(n):
+                last[0] = one_step(model, b, t)
+            return
+        errors = []
+
+        def worker(i):
+            try:
+                torch.cuda.set_device(device)
+                with torch.cuda.stream(streams[i]):
+                    for _ in range(i, n, args.inflight):
+                        last[i] = one_step(model, b, t)
+                    streams[i].synchronize()
+            except BaseException as e:      # surfaced below: a failed worker must fail the bench
+                errors.append(e)
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(args.inflight)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        if errors:
+            raise errors[0]
+
+    one_step(model, b, t)                   # fills the weight / threshold caches once, on one thread
+    torch.cuda.synchronize()
+    run_steps(args.inflight)                # every stream allocates its scratch (split-K slabs, allocator pools) once
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ret = one_step(model, b, t)
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    ret = next(r for r in last if r is not None)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -236,20 +284,38 @@ def main():
 
     roof = None
     cpu = None
+    single_ms = None
     if rank == 0:
-        probe = ConvProbe()
-        probe.install()
-        for _ in range(max(2, min(args.steps, 5))):
-            one_step(model, b, t)
-        n_launch, t_ms, nbytes, flops = probe.summary()
-        probe.remove()
-        achieved = nbytes / (t_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args), "kernel": "k_spconv",
-                "launches_per_step": n_launch // max(2, min(args.steps, 5)),
-                "avg_launch_us": round(t_ms * 1e3 / n_launch, 2),
-                "algorithmic_bytes_per_launch": int(nbytes / n_launch),
-                "achieved_tflops": round(flops / (t_ms * 1e-3) / 1e12, 2)}
+        n_probe = max(2, min(args.steps, 5)) * args.inflight
+
+        def probe_leg(runner, n):
+            probe = ConvProbe()
+            probe.install()
+            runner(n)
+            n_launch, t_ms, nbytes, flops = probe.summary()
+            probe.remove()
+            achieved = nbytes / (t_ms * 1e-3) / 1e9
+            return {"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "launches_per_step": n_launch // n, "avg_launch_us": round(t_ms * 1e3 / n_launch, 2),
+                    "algorithmic_bytes_per_launch": int(nbytes / n_launch),
+                    "achieved_tflops": round(flops / (t_ms * 1e-3) / 1e12, 2)}
+
+        # the launches are timed in the mode the timed region ran in: with several scenes in flight a launch shares the
+        # CUs with the other streams' kernels, so its own duration grows while the whole-job rate rises
+        leg = probe_leg(run_steps, n_probe)
+        roof = {"bound": "hbm", "achieved": leg.pop("achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": leg.pop("frac"), "traffic": pmc_traffic(args), "kernel": "k_spconv"}
+        roof.update(leg)
+        if args.inflight > 1:
+            def one_at_a_time(n):
+                for _ in range(n):
+                    one_step(model, b, t)
+            roof["one_scene_in_flight"] = probe_leg(one_at_a_time, max(2, min(args.steps, 5)))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            one_at_a_time(10)
+            torch.cuda.synchronize()
+            single_ms = (time.perf_counter() - t1) / 10 * 1e3
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg, model, raw)
     if dist is not None:
@@ -277,7 +343,10 @@ def main():
                                       WORKLOADS[args.workload]["voxel"] * 100, args.copies,
                                       "y" if args.copies == 1 else "ies"),
                        "points_per_step": info["n_points"], "voxels_per_step": info["n_voxels"],
-                       "proposals_per_step": n_prop, "parallelism": "1 scene per GPU, no data-path collective"},
+                       "proposals_per_step": n_prop, "scenes_in_flight_per_gpu": args.inflight,
+                       "one_scene_in_flight_ms_per_scene": None if single_ms is None else round(single_ms, 3),
+                       "parallelism": "scenes sharded over GPUs, %d in flight per GPU (host thread + HIP stream each), "
+                                      "no data-path collective" % args.inflight},
             "roofline": roof,
         }
         if cpu is not None:

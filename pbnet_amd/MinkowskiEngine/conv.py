@@ -88,11 +88,13 @@ SPLITK_WORKSPACE_BYTES = 256 << 20
 
 
 def _workspace(device):
-    """Per-device scratch for split-K launches (fp32 partial slabs), allocated once."""
-    ws = _WS.get(device)
+    """Scratch for split-K launches (fp32 partial slabs), allocated once per (device, stream): launches on one stream
+    are ordered, two scenes in flight on two streams must not share the slabs."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(SPLITK_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
-        _WS[device] = ws
+        _WS[key] = ws
     return ws
 
 

@@ -74,6 +74,8 @@ class MinkUNet(nn.Module):
         self.weight_initialization()
         self._fold_cache = {}
         self._plans = {}
+        # load_state_dict(assign=True) -- also through a parent module -- replaces the Parameter objects
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._forget_state_tensors())
 
     def _make_layer(self, planes, blocks, D):
         """Mink.py:75-107 with stride 1: a 1x1 conv + BN shortcut iff the channel count changes."""
@@ -209,8 +211,23 @@ class MinkUNet(nn.Module):
         return dict(ops=ops_arr, n_ops=len(ops), bufs=bufs_arr, n_bufs=len(bufs), out_buf=final[0], cin_p=cin_p,
                     out_width=bufs[final[0]][1], keep=keep)
 
+    def _forget_state_tensors(self):
+        self.__dict__.pop("_state_tensors", None)
+        self._plans.clear()
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .half() / .cuda() may swap the storage behind parameters: drop the tensor list and the packed plans
+        self._forget_state_tensors()
+        return super()._apply(fn, *args, **kwargs)
+
     def _plan(self, dtype):
-        ver = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        # in-place updates (optimizer steps, load_state_dict copies) bump ._version; walking the module tree for the
+        # tensors costs ~1 ms of host time per call, so the list is kept (a forward is ~2.5 ms of device time)
+        tensors = self.__dict__.get("_state_tensors")
+        if tensors is None:
+            tensors = list(self.parameters()) + list(self.buffers())
+            self.__dict__["_state_tensors"] = tensors
+        ver = tuple([t._version for t in tensors])
         hit = self._plans.get(dtype)
         if hit is None or hit[0] != ver:
             hit = (ver, self._build_plan(dtype))

@@ -135,3 +135,53 @@ def test_forward_degenerate_scenes(setup):
     with torch.no_grad():                                      # and the model is intact afterwards
         ret = model(*args, teacher=teacher)
     assert ret["proposals"][1].shape[0] > 1
+
+
+def test_scenes_in_flight(setup):
+    """Several scenes in flight on one GPU (one host thread + HIP stream each, what `bench.py --inflight` and a serving
+    loop do): every result must be bit-identical to the one-at-a-time result -- no scratch buffer, cache or table may be
+    shared between concurrent forwards."""
+    import threading
+    cfg, model, sd, _, _ = setup
+    dev = torch.device(DEV)
+    scenes = []
+    for seed, boxes in ((1, 6), (2, 4), (3, 7)):
+        b, t, _ = synth.make_val_batch(seed=seed, copies=3, room=(1.6, 1.3, 1.2), n_boxes=boxes, pitch=0.03, classes=(17, 10))
+        scenes.append(({k: torch.from_numpy(v).to(dev) for k, v in b.items()}, {k: torch.from_numpy(v).to(dev) for k, v in t.items()}))
+
+    def run(i):
+        b, t = scenes[i]
+        with torch.no_grad():
+            r = model(b["feat_voxel"], b["xyz_voxel"], b["xyz_original"], b["v2p_index"], None, 1, "test", teacher=t)
+        return [r["proposals"][0].cpu(), r["proposals"][1].cpu(), r["proposals"][3].cpu(), r["clt_scores"].cpu(),
+                r["sem_pred_p"].cpu(), r["offset_pred_p"].cpu()]
+
+    want = [run(i) for i in range(len(scenes))]
+    assert all(w[1].shape[0] > 1 for w in want)                # every scene yields proposals
+    torch.cuda.synchronize()
+    n_workers, rounds = 3, 4
+    streams = [torch.cuda.Stream(dev) for _ in range(n_workers)]
+    got, errors = [[] for _ in range(n_workers)], []
+
+    def worker(w):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[w]):
+                for r in range(rounds):
+                    for i in range(len(scenes)):
+                        j = (i + w + r) % len(scenes)
+                        got[w].append((j, run(j)))
+        except BaseException as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(n_workers)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for w in range(n_workers):
+        assert len(got[w]) == rounds * len(scenes)
+        for j, res in got[w]:
+            for a, b_ in zip(res, want[j]):
+                assert a.dtype == b_.dtype and torch.equal(a, b_), (w, j)
