@@ -11,7 +11,7 @@ workload: configs[1] -- one synthetic ScanNet-sized scene (seed 2: 161 517 point
 step    : one PBNet.forward over one scene per rank.  N > 1: every rank owns a different scene (seed 2 + rank), no
           data-path collective (scenes are independent at inference) -> weak scaling; the process group only carries
           the barrier and the max-over-ranks of the elapsed time.
-in flight: the K steps of a rank are taken round-robin by `--inflight` host threads (default 3), each on its own HIP
+in flight: the K steps of a rank are taken round-robin by `--inflight` host threads (default 4), each on its own HIP
           stream: most launches of the path are far too small for 256 CUs, so kernels of independent scenes overlap
           on the device and one scene's host read-backs hide behind another's kernels.  Results are bit-identical to
           the one-at-a-time loop (tests/test_pbnet_gpu.py::test_scenes_in_flight).  `ms_per_step` is elapsed / K (the
@@ -39,6 +39,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+# one hardware queue per in-flight stream (+ the null stream): the HIP runtime's default of 4 makes a fourth stream share
+# a queue with another one (measured: 215 instead of 286 scenes/s); must be set before the runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -208,7 +212,7 @@ def main():
     ap.add_argument("--copies", type=int, default=1, help="rotated copies per scene (reference eval uses 3: TTA)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="scenes in flight per GPU (one host thread + HIP stream each); 1 = the reference's loop")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
                     help="c2 = BASELINE configs[1] (default, the metric); c4 = configs[3], the dense 1 cm stress scene")
@@ -306,6 +310,12 @@ def main():
         roof = {"bound": "hbm", "achieved": leg.pop("achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": leg.pop("frac"), "traffic": pmc_traffic(args), "kernel": "k_spconv"}
         roof.update(leg)
+        # the same bytes against the wall clock of the whole job (SURVEY.md 8d's path-level form, convolution bytes only):
+        # what the GPU sustains across all in-flight scenes, non-convolution stages included in the time
+        conv_bytes_per_scene = roof["algorithmic_bytes_per_launch"] * roof["launches_per_step"]
+        path_gbs = conv_bytes_per_scene * args.steps / elapsed / 1e9
+        roof["path_level"] = {"conv_algorithmic_bytes_per_scene": conv_bytes_per_scene, "achieved": round(path_gbs, 1),
+                              "frac": round(path_gbs / HBM_PEAK_GBS, 4)}
         if args.inflight > 1:
             def one_at_a_time(n):
                 for _ in range(n):
