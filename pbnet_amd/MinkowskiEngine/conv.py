@@ -93,6 +93,8 @@ def _workspace(device):
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
+        while len(_WS) >= 16:               # streams come and go in a serving loop: drop the oldest entry (its block goes
+            _WS.pop(next(iter(_WS)))        # back to the pool of the stream it was allocated on, which orders any reuse)
         ws = torch.empty(SPLITK_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
         _WS[key] = ws
     return ws
