@@ -21,6 +21,25 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def gather_scene_results(local, dst=0):
+    """The one optional exchange of the inference path: every rank's per-scene records -- {scene name:
+    record}, e.g. evaluate.SceneMatches -- merged on rank `dst` so that the AP of the whole validation set is computed
+    once (eval_map.py:149-151 does it in its single process).  A scene that two ranks evaluated (the wrap-around padding
+    of shard_scenes) is kept once, from the lower rank.  Returns the merged dict on `dst`, None elsewhere."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dict(local)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    parts = [None] * world if rank == dst else None
+    dist.gather_object(dict(local), parts, dst=dst)
+    if rank != dst:
+        return None
+    merged = {}
+    for part in parts:
+        for scene, rec in part.items():
+            merged.setdefault(scene, rec)
+    return merged
+
+
 def allreduce_gradients(params, bucket_bytes=64 << 20):
     """Average gradients across ranks in flat buckets (>= 64 MB keeps a ring on 7 x 153 GB/s xGMI links bandwidth-
     rather than latency-bound).  Parameters without a gradient on this rank (the mask/score

@@ -57,3 +57,37 @@ def test_shard_single_rank_is_identity():
     assert pd.shard_scenes(4, 0, 1) == [0, 1, 2, 3]
     assert pd.shard_scenes(0, 0, 2) == []
     assert pd.max_over_ranks(3.5) == 3.5
+
+
+def _eval_worker(rank, world, port, out):
+    """Sharded validation: each rank associates its scenes, rank 0 merges and computes the AP of the whole set."""
+    import numpy as np
+    from pbnet_amd import evaluate as E
+    from tests.test_oracle_eval import CASES, _record
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(CASES[1])                                           # E2: three scenes
+    mine = pd.shard_scenes(int(g["n_scenes"]), rank, world)         # rank 0: [0, 2], rank 1: [1, 0] (wrap-around)
+    local = {}
+    for s in mine:
+        rec = _record(g, s)
+        if rank == 1 and s == 0:
+            rec.pred_conf = rec.pred_conf * 0                       # the duplicate must lose against rank 0's copy
+        local[rec.scene] = rec
+    merged = pd.gather_scene_results(local)
+    if rank == 0:
+        ap = E.evaluate_matches(merged)
+        same = np.array_equal(np.isnan(ap), np.isnan(g["ap"])) and np.array_equal(np.nan_to_num(ap), np.nan_to_num(g["ap"]))
+        out[0] = (sorted(merged) == ["scene%04d_00" % s for s in range(3)], bool(same))
+    else:
+        out[rank] = (merged is None, True)
+    dist.destroy_process_group()
+
+
+def test_sharded_validation_merges_on_rank0():
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_eval_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert out[0] == (True, True) and out[1] == (True, True)
+    assert pd.gather_scene_results({"a": 1}) == {"a": 1}           # no process group: identity
