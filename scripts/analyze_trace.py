@@ -3,7 +3,17 @@ number of kernels running, and per kernel family the time it ran alone / its sha
 usage: analyze_trace.py <kernel_trace.csv> [skip_fraction]"""
 import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
-ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows]
+def fill(r):
+    """Rough share of the 256 CUs a launch can keep busy: workgroups / (CUs x resident workgroups per CU by LDS/waves)."""
+    try:
+        wg = max(1, int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"]))
+        grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]); lds = int(r.get("LDS_Block_Size", 0) or 0)
+    except (KeyError, ValueError):
+        return 1.0
+    n_wg = max(1, grid // wg)
+    per_cu = max(1, min(32 * 64 // wg, (160 * 1024) // lds if lds > 0 else 32))
+    return min(1.0, n_wg / (256.0 * per_cu))
+ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], fill(r)) for r in rows]
 ev.sort()
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.35
 t_lo = ev[0][0] + (ev[-1][1] - ev[0][0]) * skip
@@ -17,8 +27,15 @@ def fam(n):
         n2 = "k_spconv<NT=%s>" % (t.group(2) if t else "?")
     return n2[:40]
 pts = []
-for s, e, n in ev:
+fills = []
+for s, e, n, f in ev:
     pts.append((s, 1, fam(n))); pts.append((e, -1, fam(n)))
+    fills.append((s, f)); fills.append((e, -f))
+fills.sort()
+cur = 0.0; lastt = fills[0][0]; area = 0.0; capped = 0.0
+for t, d in fills:
+    area += cur * (t - lastt); capped += min(cur, 1.0) * (t - lastt); lastt = t; cur += d
+print("sum of launch fill factors over the window: mean %.2f GPUs demanded, %.1f%% of the CU capacity coverable" % (area / (fills[-1][0] - fills[0][0]), 100 * capped / (fills[-1][0] - fills[0][0])))
 pts.sort(key=lambda p: (p[0], p[1]))
 running = collections.Counter(); nrun = 0
 hist = collections.Counter(); alone = collections.Counter(); ksec = collections.Counter()
