@@ -324,11 +324,33 @@ class SparseTensor(object):
             coordinate_manager = cm
             tensor_stride = 1
         self._F = features
+        self._stored = None
         self.coordinate_manager = coordinate_manager
         self.tensor_stride = int(tensor_stride)
 
+    @classmethod
+    def _from_stored_rows(cls, stored, row_index, coordinate_manager, tensor_stride=1):
+        """Features kept in another row order (the fused U-Net computes in Z-order): row i of this tensor is
+        stored[row_index[i]].  `.F` materialises that gather on first use; consumers that index rows anyway take
+        `rows()` and fold `row_index` into their own index instead."""
+        self = cls.__new__(cls)
+        self._F = None
+        self._stored = (stored, row_index)
+        self.coordinate_manager = coordinate_manager
+        self.tensor_stride = int(tensor_stride)
+        return self
+
+    def rows(self):
+        """(features, row_index): row i is features[row_index[i]] (row_index None = rows are in place)."""
+        if self._F is None:
+            return self._stored
+        return self._F, None
+
     @property
     def F(self):
+        if self._F is None:
+            stored, row_index = self._stored
+            self._F = stored[row_index]
         return self._F
 
     @property
@@ -341,21 +363,22 @@ class SparseTensor(object):
 
     @property
     def device(self):
-        return self._F.device
+        return self.rows()[0].device
 
     @property
     def dtype(self):
-        return self._F.dtype
+        return self.rows()[0].dtype
 
     @property
     def shape(self):
-        return self._F.shape
+        f, idx = self.rows()
+        return f.shape if idx is None else torch.Size((idx.shape[0], f.shape[1]))
 
     def replace_feature(self, feats):
         return SparseTensor(feats, coordinate_manager=self.coordinate_manager, tensor_stride=self.tensor_stride)
 
     def __repr__(self):
-        return "SparseTensor(F=%s, stride=%d)" % (tuple(self._F.shape), self.tensor_stride)
+        return "SparseTensor(F=%s, stride=%d)" % (tuple(self.shape), self.tensor_stride)
 
 
 def cat(*tensors):

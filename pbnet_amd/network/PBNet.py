@@ -109,12 +109,14 @@ class PBNet(nn.Module):
         if fused:
             # heads evaluated straight at the points (one launch each): the same rows, so the same numbers, as
             # evaluating them at the voxels and gathering (PBNet.py:124-134)
-            f = point_feat.F
+            f, row_index = point_feat.rows()              # the U-Net's own row order: fold it into the point index
+            if row_index is not None:
+                v2p = row_index[v2p]
             out = {
                 "point_feat_p": f[v2p],
                 "sem_pred_score_p": stage_ops.mlp_rows(self.linear_sem, f, v2p),
                 "offset_pred_p": stage_ops.mlp_rows(self.linear_offset, f, v2p),
-                "batch_head_p": xyz_voxel[:, 0].to(torch.int32)[v2p],
+                "batch_head_p": xyz_voxel[:, 0].to(torch.int32)[v2p_v1.long()],
             }
             _sec.__exit__(None, None, None)
             return out
@@ -291,7 +293,8 @@ class PBNet(nn.Module):
             inputs_v2 = ME.SparseTensor(feat, coords)
         with section("a18_mask_unet"):
             if fused_glue:   # head evaluated at the rows (PBNet.py:247): same numbers as head-then-gather, one launch
-                mask_score = stage_ops.mlp_rows(self.linear_binary, self.D_Unet(inputs_v2).F, inputs_v2.inverse_mapping)
+                f2, row_index = self.D_Unet(inputs_v2).rows()
+                mask_score = stage_ops.mlp_rows(self.linear_binary, f2, inputs_v2.inverse_mapping, row_index)
             else:
                 mask_score = self.linear_binary(self.D_Unet(inputs_v2)).F[inputs_v2.inverse_mapping]   # [R, 1]
         if task != "test":
@@ -322,7 +325,7 @@ class PBNet(nn.Module):
                 inputs_v3 = ME.SparseTensor(feat3, coords3)
             with section("a20_score_unet"):
                 if fused_glue:
-                    iou_feat_f = stage_ops.mlp_rows(self.linear_IOU_feat, self.score_Unet(inputs_v3).F)
+                    iou_feat_f = stage_ops.mlp_rows(self.linear_IOU_feat, *self.score_Unet(inputs_v3).rows())
                 else:
                     iou_feat = self.linear_IOU_feat(self.score_Unet(inputs_v3))
             with section("a20_pool_head"):

@@ -284,10 +284,11 @@ class MinkUNet(nn.Module):
         o = offs[plan["out_buf"]]
         width = plan["out_width"]
         out = arena[o:o + rows[0] * width * feats.element_size()].view(dt).view(rows[0], width)
-        if sv is not None:
-            out = out[sv.inv_perm]                         # back to the external row order
         cout = self.final_sematic.kernel.shape[-1]
-        return ME.SparseTensor(out if width == cout else out[:, :cout], coordinate_manager=cm, tensor_stride=1)
+        out = out if width == cout else out[:, :cout]
+        if sv is not None:                                 # rows are in Z-order: external row i = out[inv_perm[i]]
+            return ME.SparseTensor._from_stored_rows(out, sv.inv_perm, cm)
+        return ME.SparseTensor(out, coordinate_manager=cm, tensor_stride=1)
 
     def _forward_fused_py(self, x):
         """The same fused forward issued launch by launch from Python (kept as a cross-check of the native plan)."""
