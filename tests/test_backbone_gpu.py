@@ -301,3 +301,49 @@ def test_loader_voxelize_batch_matches_per_scene_quantize_and_collate():
     assert np.array_equal(xv.cpu().numpy(), np.concatenate(want_c))
     assert np.array_equal(fv.cpu().numpy(), np.concatenate(want_f))
     assert np.array_equal(v2p.cpu().numpy(), np.concatenate(want_v2p))
+
+
+def _brute_kernel_map(coords, stride, k):
+    """nbr[row, kk] by dictionary lookup, ME conventions (x fastest, odd kernels centred, even not)."""
+    index = {tuple(c): i for i, c in enumerate(coords.tolist())}
+    c0 = k // 2 if k % 2 else 0
+    out = np.full((len(coords), k ** 3), -1, np.int64)
+    for kk in range(k ** 3):
+        d = np.array([0, (kk % k - c0) * stride, (kk // k % k - c0) * stride, (kk // (k * k) - c0) * stride])
+        for i, c in enumerate(coords):
+            out[i, kk] = index.get(tuple((c + d).tolist()), -1)
+    return out
+
+
+@pytest.mark.parametrize("mode", ["sorted", "plain"])
+def test_kernel_maps_in_z_order_and_external_order(mode):
+    """pbn_kernel_map_cube on the Z-ordered lineage and on the external order against a dictionary look-up: every level,
+    odd and even kernels, negative coordinates, batch seams, a tensor stride the rows are not multiples of."""
+    coords = _scene_coords(43, room=(0.7, 0.6, 0.5), n_boxes=2, batch=3)
+    coords[:, 1:] -= np.array([9, 4, 2], np.int32)                    # part of the scene at negative coordinates
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(DEV))
+    pyr = cm.sorted().pyramid if mode == "sorted" else cm.plain()
+    for s in (1, 2, 4, 8, 16):
+        lvl = pyr.coordinates(s).cpu().numpy()
+        assert (lvl[:, 1:] % s == 0).all()
+        for k in ((3, 5) if s == 1 else (3,)):
+            got = pyr.kernel_map(s, k).cpu().numpy()
+            assert np.array_equal(got, _brute_kernel_map(lvl, s, k)), (mode, s, k)
+    # the C entry point on its own: even kernels, and a tensor stride the rows are NOT multiples of; rows in blocked or
+    # external order
+    from pbnet_amd import _native as N
+    lib = N.lib()
+    order = np.lexsort((coords[:, 3], coords[:, 2], coords[:, 1], coords[:, 3] >> 3, coords[:, 2] >> 3, coords[:, 1] >> 3,
+                        coords[:, 0])) if mode == "sorted" else np.arange(len(coords))
+    blocked = np.ascontiguousarray(coords[order])
+    p0 = ME.CoordinateManager(torch.from_numpy(blocked).to(DEV)).plain()
+    p0.finalize()
+    lvl0 = p0.coordinates(1)
+    assert np.array_equal(lvl0.cpu().numpy(), blocked)
+    n, L = int(lvl0.shape[0]), p0.layout
+    for k, stride in ((2, 1), (4, 1), (3, 2), (2, 3)):
+        nbr = torch.full((n, k ** 3), -7, dtype=torch.int32, device=DEV)
+        N.check(lib.pbn_kernel_map_cube(N.ptr(lvl0), None, n, k, stride, 1, N.c_vp(p0.ptr(L.keys[0])),
+                                        N.c_vp(p0.ptr(L.vals[0])), L.capacity[0], N.ptr(nbr), N.current_stream()),
+                "pbn_kernel_map_cube")
+        assert np.array_equal(nbr.cpu().numpy(), _brute_kernel_map(blocked, stride, k)), (mode, k, stride)
