@@ -25,6 +25,7 @@ from .Mink import Mink_unet as unet3d
 COUNT_MEAN = [-1., -1., 3917., 12056., 2303., 8331., 3948., 3166., 5629., 11719., 1003., 3317., 4912., 10221., 3889.,
               4136., 2120., 945., 3967., 2589.]                       # PBNet.py:33-34 (softgroup & HAIS)
 LOCAL_VOXEL = 0.02                                                    # PBNet.py:236 (hard-coded)
+HEAD_CLUSTERS = 256                                                   # clusters whose centres travel with the first grouping read-back
 MASK_THD = 0.45                                                       # PBNet.py:317
 
 
@@ -193,7 +194,12 @@ class PBNet(nn.Module):
         with section("a7_16_grouping"):
             res = pbnet_ops.cluster_device(ins_offseted, ins_orig, ins_sem, seg_len, self.radius, self.min_pts)
             mark("a7:grouping queued")
-            head = torch.cat([res.n_clusters, res.cluster_num]).cpu().numpy()        # sync 2
+            # one read-back for the cluster table AND the first HEAD_CLUSTERS centres / member offsets (a scene has tens
+            # of clusters; a second read-back follows only when there are more)
+            n_seg = int(res.cluster_num.shape[0])
+            hc = min(HEAD_CLUSTERS, int(res.member_start.shape[0]) - 1)
+            head = torch.cat([res.n_clusters, res.cluster_num, res.member_start[:hc + 1],
+                              res.centers[:3 * hc].view(torch.int32)]).cpu().numpy()   # sync 2
             mark("a7:grouping done")
             n_clt = int(head[0])
         if n_clt < 0:
@@ -201,11 +207,15 @@ class PBNet(nn.Module):
         if n_clt == 0:
             return self._empty_stage(dev, task)
         _sec = section("a17_plan"); _sec.__enter__()
-        cluster_num = head[1:].reshape(len(classes), nb).tolist()
-        packed = torch.cat([res.centers[:3 * n_clt], res.member_start[:n_clt + 1].view(torch.float32)]).cpu()  # sync 3
+        cluster_num = head[1:1 + n_seg].reshape(len(classes), nb).tolist()
+        if n_clt <= hc:
+            member_start = head[1 + n_seg:1 + n_seg + n_clt + 1]
+            centers = torch.from_numpy(head[2 + n_seg + hc:2 + n_seg + hc + 3 * n_clt].view(np.float32).copy()).view(n_clt, 3)
+        else:
+            packed = torch.cat([res.centers[:3 * n_clt], res.member_start[:n_clt + 1].view(torch.float32)]).cpu()  # sync 3
+            centers = packed[:3 * n_clt].view(n_clt, 3)
+            member_start = packed[3 * n_clt:].view(torch.int32).numpy()
         mark("a17:centres on host")
-        centers = packed[:3 * n_clt].view(n_clt, 3)
-        member_start = packed[3 * n_clt:].view(torch.int32).numpy()
         sizes = (member_start[1:] - member_start[:-1])
         sizes_l = sizes.tolist()
         labels_h = None
