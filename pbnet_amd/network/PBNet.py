@@ -80,6 +80,8 @@ class PBNet(nn.Module):
         """teacher: optional dict(sem_score [N,sem_num], offset [N,3]) that REPLACES the two head outputs after they
         have been computed -- a bench/test hook: randomly initialised heads cannot produce instances."""
         dev = torch.device("cuda", torch.cuda.current_device())
+        if feat_voxel.shape[0] == 0 or xyz_original.shape[0] == 0:
+            raise ValueError("PBNet.forward: empty scene (0 voxels / 0 points)")
         fused = not torch.is_grad_enabled()           # inference: the stage glue runs as fused launches (stage_ops)
         stage1 = self.backbone_stage(feat_voxel.to(dev), xyz_voxel.to(dev), v2p_v1.to(dev), fused)
         if teacher is not None:

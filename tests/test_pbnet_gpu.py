@@ -185,3 +185,38 @@ def test_scenes_in_flight(setup):
         for j, res in got[w]:
             for a, b_ in zip(res, want[j]):
                 assert a.dtype == b_.dtype and torch.equal(a, b_), (w, j)
+
+
+def test_degenerate_inputs_return_or_raise(setup):
+    """Inputs far from a room scan must come back well-formed or raise -- never hang, never read out of bounds."""
+    cfg, model, _, _, _ = setup
+    rng = np.random.default_rng(0)
+
+    def run(xyz, cls):
+        n = xyz.shape[0]
+        q = np.floor(xyz / 0.02).astype(np.int32)
+        uq, inv = np.unique(q, axis=0, return_inverse=True) if n else (np.zeros((0, 3), np.int32), np.zeros(0, np.int64))
+        coords = np.concatenate([np.zeros((len(uq), 1), np.int32), uq], 1).astype(np.int32)
+        sc = np.full((n, 20), -5.0, np.float32)
+        sc[np.arange(n), cls] = 5.0
+        t = {"sem_score": torch.from_numpy(sc).to(DEV), "offset": torch.zeros(n, 3, device=DEV)}
+        with torch.no_grad():
+            r = model(torch.zeros(len(uq), 6, device=DEV), torch.from_numpy(coords).to(DEV),
+                      torch.from_numpy(xyz.astype(np.float32)).to(DEV), torch.from_numpy(inv.reshape(-1).astype(np.int64)).to(DEV),
+                      None, 1, "test", teacher=t)
+        torch.cuda.synchronize()
+        idx, off = r["proposals"][0], r["proposals"][1]
+        assert r["sem_pred_p"].shape[0] == n and off[-1].item() == idx.shape[0] and r["clt_scores"].shape[0] == off.shape[0] - 1
+        assert idx.shape[0] == 0 or (0 <= int(idx[:, 1].min()) and int(idx[:, 1].max()) < n)
+        return int(off.shape[0]) - 1
+
+    with pytest.raises(ValueError):
+        run(np.zeros((0, 3)), 0)
+    with pytest.raises(ValueError):                                     # 700 m / 2 cm does not fit 16 bits
+        run(np.array([[700.0, 0, 0], [0, 0, 0]]), 3)
+    assert run(np.array([[0.1, 0.2, 0.3]]), 5) == 0                     # one point: below every class's population gate
+    assert run(rng.random((500, 3)) * 0.019, 5) >= 1                    # 500 points in one voxel: one dense core
+    assert run(np.tile([[0.5, 0.5, 0.5]], (500, 1)), 7) >= 1            # 500 identical points
+    run(np.stack([np.linspace(0, 3, 3000), np.zeros(3000), np.zeros(3000)], 1), 4)      # a line
+    assert run(rng.random((4000, 3)) * 0.5 - 2.0, 9) == 0               # sparse cloud at negative coordinates: no core
+    assert run(np.concatenate([rng.random((3000, 3)) * 0.1, rng.random((3000, 3)) * 0.1 + 5.0]), 19) >= 2   # two far blobs
