@@ -347,3 +347,30 @@ def test_kernel_maps_in_z_order_and_external_order(mode):
                                         N.c_vp(p0.ptr(L.vals[0])), L.capacity[0], N.ptr(nbr), N.current_stream()),
                 "pbn_kernel_map_cube")
         assert np.array_equal(nbr.cpu().numpy(), _brute_kernel_map(blocked, stride, k)), (mode, k, stride)
+
+
+def test_unet_forward_is_graph_capturable_fp16(golden_dir):
+    """BASELINE configs[4]: fp16 feature slabs, int32 coordinates, the U-Net forward captured in a HIP graph.  With the
+    coordinate pyramid built (its row counts on the host) the fused forward is a fixed sequence of launches on the
+    current stream -- no allocation-by-size decision, no read-back -- so it captures, and a replay reproduces the
+    eagerly launched result bit for bit; fp16 stays close to the fp32 golden."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_backbone_golden as G
+    g = dict(np.load(os.path.join(golden_dir, "backbone_MinkUNet34C.npz")))
+    m = G.build("MinkUNet34C", g["feats"].shape[1]).to(DEV).eval()
+    x = ME.SparseTensor(torch.from_numpy(g["feats"]).to(torch.float16), torch.from_numpy(g["coords"]), device=DEV)
+    assert x.C.dtype == torch.int32
+    with torch.no_grad():
+        eager = m(x).F.clone()                       # also builds the pyramid, packs the weights, sizes the scratch
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = m(x).F
+        for _ in range(3):
+            out.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, eager)
+    want = torch.from_numpy(g["out_eval"])
+    assert ((out.float().cpu() - want).norm() / want.norm()).item() < 5e-3
