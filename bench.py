@@ -8,9 +8,9 @@ workload: configs[1] -- one synthetic ScanNet-sized scene (seed 2: 161 517 point
           the reference's init rule).  Randomly initialised heads cannot produce instances, so the semantic / offset
           head outputs are overwritten by teacher-forced values AFTER they have been computed; every
           stage of the path therefore runs inside the timed region on realistic, data-dependent sizes.
-step    : one PBNet.forward over one scene per rank.  N > 1: every rank owns a different scene (seed 2 + rank), no
-          data-path collective (scenes are independent at inference) -> weak scaling; the process group only carries
-          the barrier and the max-over-ranks of the elapsed time.
+step    : one PBNet.forward over one scene per rank.  N > 1: every rank owns its own copy of the scene (identical
+          per-GPU work), no data-path collective (scenes are independent at inference) -> weak scaling; the process
+          group only carries the barrier and the max-over-ranks of the elapsed time.
 in flight: the K steps of a rank are taken round-robin by `--inflight` host threads (default 4), each on its own HIP
           stream: most launches of the path are far too small for 256 CUs, so kernels of independent scenes overlap
           on the device and one scene's host read-backs hide behind another's kernels.  Results are bit-identical to
@@ -64,8 +64,9 @@ def build_workload(rank, copies, dtype, device, workload="c2"):
     cfg = get_config(test=True)
     torch.manual_seed(22)  # /root/reference/config/config.py:15
     model = PBNet(cfg).to(device).eval()
+    # weak scaling: per-GPU work is fixed, so every rank holds its own copy of the SAME scene (other seeds of the
+    # generator give scenes of 148-161 k voxels, and the slowest rank would set the time of the whole job)
     w = dict(WORKLOADS[workload])
-    w["seed"] += rank
     batch, teacher, info = synth.make_val_batch(copies=copies, **w)
     b = {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
     b["feat_voxel"] = b["feat_voxel"].to(dtype)
