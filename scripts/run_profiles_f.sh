@@ -1,5 +1,5 @@
 #!/bin/bash
-# r01_f: default bench (3 scenes in flight) + rocprofv3 kernel stats of the same command + one-scene-in-flight stats
+# r01_f: default bench (scenes in flight) + rocprofv3 kernel stats of the same command + one-scene-in-flight stats
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_f
