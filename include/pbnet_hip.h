@@ -160,7 +160,8 @@ int pbn_spconv_forward(const void* in_feat, int ld_in, const int32_t* nbr, int n
                        int relu, void* out_feat, int ld_out, int dtype, int rows_per_wave, void* workspace,
                        size_t workspace_bytes, pbn_stream_t stream);
 
-/* out[i, :] = in[idx[i], :] on 16-byte multiples (voxel -> point gathers, network/PBNet.py:130-134,250). */
+/* out[i, :] = in[idx[i], :] on 16-byte multiples (voxel -> point gathers, network/PBNet.py:130-134,250); a negative
+ * index gives a zero row (padding slots of the compacted weight-gradient operands). */
 int pbn_gather_rows(const void* in, int ld_in_bytes, const int64_t* idx, int n, int row_bytes, void* out,
                     int ld_out_bytes, pbn_stream_t stream);
 
@@ -210,6 +211,18 @@ int pbn_pack_weight(const float* src, int n_offsets, int dim_a, int dim_b, int f
  * [n, kc, row_bytes].  dW[k0:k0+kc] is then one dense contraction of this slab with the output gradient. */
 int pbn_gather_rulebook_rows(const void* in, int ld_in_bytes, int row_bytes, const int32_t* nbr, int n_offsets, int k0,
                              int kc, int n, void* out, pbn_stream_t stream);
+
+/* Offset-major pair lists of an output-stationary map (training, BASELINE configs[2]): the rule pairs of ME's
+ * convolution weight gradient, dW[k] = sum over pairs (i, o) of offset k of x[i]^T g[o].
+ *   pbn_rulebook_pair_counts : table int32[pbn_rulebook_pair_blocks(n), K] (per-block prefix counts, kept for the fill)
+ *                              and totals int32[K] (pairs per offset) -- the caller reads the totals back, gives every
+ *                              offset ceil(total/seg) segments of `seg` pairs and passes their first-segment indices
+ *   pbn_rulebook_pair_fill   : in_idx / out_idx int64[n_segments * seg] (-1 = padding), seg_offset int64[n_segments]
+ * Pairs of an offset keep ascending output-row order; positions are prefix counts (no atomics): deterministic. */
+int pbn_rulebook_pair_blocks(int n);
+int pbn_rulebook_pair_counts(const int32_t* nbr, int n, int n_offsets, int32_t* table, int32_t* totals, pbn_stream_t stream);
+int pbn_rulebook_pair_fill(const int32_t* nbr, int n, int n_offsets, const int32_t* table, const int32_t* seg_start, int seg,
+                           int n_segments, int64_t* in_idx, int64_t* out_idx, int64_t* seg_offset, pbn_stream_t stream);
 
 /* pbn_mlp_rows -- the two-layer heads of network/PBNet.py:43-82 in eval mode, one launch per head:
  *   out[i, 0:n_out] = act( W2 . prelu( (W1 . x) * scale + shift ) + b2 ),   x = in[row(i), 0:channels],

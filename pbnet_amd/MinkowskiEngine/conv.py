@@ -5,7 +5,9 @@ Mirrors the constructor signatures and parameter names the reference uses from M
 [K^3,Cin,Cout] or [Cin,Cout] and optional `.bias` [1,Cout]; network/PBNet.py:43-82: MinkowskiLinear with `.linear`).
 """
 import math
+import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -140,15 +142,100 @@ def _pad_vec(v, cout_p, fill):
 
 
 WGRAD_CHUNK_BYTES = 192 << 20
+WGRAD_PAIR_SEGMENT = 4096         # rule pairs per batched-GEMM segment of the compacted weight gradient
+
+
+def _gather_rows(src, idx):
+    """out[i] = src[idx[i]] (zero row for idx < 0), 16-byte rows, one launch (pbn_gather_rows)."""
+    es = src.element_size()
+    out = torch.empty(idx.shape[0], src.shape[1], dtype=src.dtype, device=src.device)
+    N.check(N.lib().pbn_gather_rows(N.c_vp(src.data_ptr()), src.stride(0) * es, N.ptr(idx), int(idx.shape[0]),
+                                    src.shape[1] * es, N.c_vp(out.data_ptr()), src.shape[1] * es, N.current_stream()),
+            "pbn_gather_rows")
+    return out
+
+
+def rulebook_pairs(nbr, segment=WGRAD_PAIR_SEGMENT):
+    """The map as offset-major lists of (input row, output row) pairs cut into segments of `segment` pairs, -1 padded:
+    (in_idx, out_idx) int64 [segments * segment], seg_offset int64 [segments], segments.  One read-back (pairs per
+    offset) sizes the lists.  Cached on the map tensor: every layer of a level shares its map."""
+    hit = getattr(nbr, "_pbn_pairs", None)
+    if hit is not None and hit[4] == segment:
+        return hit[:4]
+    N.require_cuda(nbr)
+    assert nbr.dtype == torch.int32 and nbr.is_contiguous()
+    lib = N.lib()
+    v, k = int(nbr.shape[0]), int(nbr.shape[1])
+    dev = nbr.device
+    table = torch.empty(max(lib.pbn_rulebook_pair_blocks(v), 1) * k, dtype=torch.int32, device=dev)
+    totals = torch.empty(k, dtype=torch.int32, device=dev)
+    st = N.current_stream()
+    N.check(lib.pbn_rulebook_pair_counts(N.ptr(nbr), v, k, N.ptr(table), N.ptr(totals), st), "pbn_rulebook_pair_counts")
+    cnt = totals.cpu().numpy().astype(np.int64)                                  # the one read-back
+    segs = (cnt + segment - 1) // segment
+    seg_start = np.concatenate([[0], np.cumsum(segs)[:-1]]).astype(np.int32)
+    n_seg = int(segs.sum())
+    in_idx = torch.empty(n_seg * segment, dtype=torch.int64, device=dev)
+    out_idx = torch.empty(n_seg * segment, dtype=torch.int64, device=dev)
+    seg_offset = torch.empty(n_seg, dtype=torch.int64, device=dev)
+    N.check(lib.pbn_rulebook_pair_fill(N.ptr(nbr), v, k, N.ptr(table), N.ptr(torch.from_numpy(seg_start).to(dev)), segment,
+                                       n_seg, N.ptr(in_idx), N.ptr(out_idx), N.ptr(seg_offset), st), "pbn_rulebook_pair_fill")
+    hit = (in_idx, out_idx, seg_offset, n_seg, segment)
+    try:
+        nbr._pbn_pairs = hit
+    except AttributeError:
+        pass
+    return hit[:4]
+
+
+def _bmm_f32(a, b):
+    """Batched GEMM with an fp32 result (rocBLAS accumulates in fp32; keep it when this torch can return it)."""
+    if a.dtype == torch.float32:
+        return torch.bmm(a, b)
+    global _BMM_OUT_DTYPE
+    if _BMM_OUT_DTYPE is None:
+        try:
+            torch.bmm(a[:1, :1, :1], b[:1, :1, :1], out_dtype=torch.float32)
+            _BMM_OUT_DTYPE = True
+        except (TypeError, RuntimeError):
+            _BMM_OUT_DTYPE = False
+    return torch.bmm(a, b, out_dtype=torch.float32) if _BMM_OUT_DTYPE else torch.bmm(a, b).float()
+
+
+_BMM_OUT_DTYPE = None
+
+
+def _wgrad_compact(f, g, nbr, cin, cout):
+    """dW from the compacted pair lists: both operands gathered pair by pair (no rows for absent neighbours: a centred
+    3x3x3 map is ~26 % populated), one batched GEMM over the segments (fp32 accumulation), segments summed per offset."""
+    in_idx, out_idx, seg_offset, n_seg = rulebook_pairs(nbr)
+    c = WGRAD_PAIR_SEGMENT
+    dw = torch.zeros(nbr.shape[1], cin, cout, dtype=torch.float32, device=f.device)
+    seg_per_pass = max(1, WGRAD_CHUNK_BYTES // (c * (cin + cout) * f.element_size()))
+    for s0 in range(0, n_seg, seg_per_pass):
+        s1 = min(n_seg, s0 + seg_per_pass)
+        x = _gather_rows(f, in_idx[s0 * c:s1 * c]).view(s1 - s0, c, cin)
+        y = _gather_rows(g, out_idx[s0 * c:s1 * c]).view(s1 - s0, c, cout)
+        dw.index_add_(0, seg_offset[s0:s1], _bmm_f32(x.transpose(1, 2), y))
+    return dw
 
 
 def _wgrad(feats, grad_out, nbr, cin, cout):
-    """dW[k] = sum over rule pairs (i, o) at offset k of feats[i]^T grad_out[o]: a row gather followed by ONE plain
-    dense GEMM per offset chunk ([kc*Cin, V] x [V, Cout], rocBLAS through torch.matmul -- the contraction itself has no
-    sparse structure left once the rows are gathered).  fp32 result."""
+    """dW[k] = sum over rule pairs (i, o) at offset k of feats[i]^T grad_out[o].  Rows of both operands are gathered
+    through the offset-major pair lists (pbn_rulebook_pair_*) and contracted by one batched library GEMM (rocBLAS through
+    torch.bmm -- the contraction itself has no sparse structure left once the rows are gathered); operands whose rows
+    are not whole 16-byte vectors (the 6-channel stem) take the dense-slab form below.  fp32 result."""
     if nbr is None:
         return (feats[:, :cin].t() @ grad_out[:, :cout]).float().unsqueeze(0)
     v, k = nbr.shape
+    es = feats.element_size()
+    if (cin * es) % 16 == 0 and (cout * es) % 16 == 0 and feats.stride(1) == 1 and (feats.stride(0) * es) % 16 == 0 \
+            and feats.data_ptr() % 16 == 0 and nbr.is_contiguous() and os.environ.get("PBN_WGRAD_DENSE", "0") != "1":
+        f = feats if feats.shape[1] == cin else feats[:, :cin]
+        g = grad_out if grad_out.shape[1] == cout else grad_out[:, :cout]
+        if g.stride(1) != 1 or (g.stride(0) * es) % 16 or g.data_ptr() % 16:
+            g = g.contiguous()
+        return _wgrad_compact(f, g, nbr, cin, cout)
     dw = torch.empty(k, cin, cout, dtype=torch.float32, device=feats.device)
     f = feats[:, :cin]
     g = grad_out[:, :cout].contiguous()

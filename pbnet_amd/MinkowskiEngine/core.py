@@ -83,23 +83,32 @@ class _Pyramid(object):
         l = self.level_index(stride)
         return self.view(self.layout.coords[l], self.n[l] * 4, torch.int32, (self.n[l], 4))
 
+    def _map_view(self, key, make):
+        """One tensor object per map for the life of the pyramid: per-map derived tables (the weight gradient's pair
+        lists) are cached on the object and shared by every layer of the level."""
+        views = self.__dict__.setdefault("_views", {})
+        if key not in views:
+            views[key] = make()
+        return views[key]
+
     def kernel_map(self, stride, kernel_size):
         self.finalize()
         l = self.level_index(stride)
         if kernel_size == 3:
-            return self.view(self.layout.k3[l], self.n[l] * 27, torch.int32, (self.n[l], 27))
+            return self._map_view(("k3", l), lambda: self.view(self.layout.k3[l], self.n[l] * 27, torch.int32, (self.n[l], 27)))
         assert kernel_size == 5 and stride == 1
-        return self.view(self.layout.k5, self.n[0] * 125, torch.int32, (self.n[0], 125))
+        return self._map_view(("k5",), lambda: self.view(self.layout.k5, self.n[0] * 125, torch.int32, (self.n[0], 125)))
 
     def down_map(self, stride_in):
         self.finalize()
         l = self.level_index(stride_in)
-        return self.view(self.layout.nbr_down[l], self.n[l + 1] * 8, torch.int32, (self.n[l + 1], 8))
+        return self._map_view(("down", l), lambda: self.view(self.layout.nbr_down[l], self.n[l + 1] * 8, torch.int32,
+                                                             (self.n[l + 1], 8)))
 
     def up_map(self, stride_in):
         self.finalize()
         l = self.level_index(stride_in) - 1
-        return self.view(self.layout.up[l], self.n[l] * 8, torch.int32, (self.n[l], 8))
+        return self._map_view(("up", l), lambda: self.view(self.layout.up[l], self.n[l] * 8, torch.int32, (self.n[l], 8)))
 
     def native_tables(self):
         self.finalize()

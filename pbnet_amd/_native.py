@@ -94,6 +94,9 @@ SIGNATURES = {
                                       c_vp]),
     "pbn_bitmask_to_dense": (c_int, [c_vp, c_i32p, c_int, c_int, c_i32p, c_vp]),
     "pbn_instance_overlap": (c_int, [c_i32p, c_int, c_int, c_i32p, c_int, c_i32p, c_vp]),
+    "pbn_rulebook_pair_blocks": (c_int, [c_int]),
+    "pbn_rulebook_pair_counts": (c_int, [c_i32p, c_int, c_int, c_i32p, c_i32p, c_vp]),
+    "pbn_rulebook_pair_fill": (c_int, [c_i32p, c_int, c_int, c_i32p, c_i32p, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "pbn_gather_rulebook_rows": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "pbn_pack_weight": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "pbn_kernel_map_cube": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),

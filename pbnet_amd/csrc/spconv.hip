@@ -564,14 +564,15 @@ int launch_t(const ConvArgs& a, int rows_per_wave, float* ws, size_t wsb, hipStr
     return launch_nt<T, 1>(a, ws, wsb, stream);
 }
 
-// ---- row gather: out[i, :] = in[idx[i], :]  (voxel -> point, PBNet.py:130-134) ----------------------------------
+// ---- row gather: out[i, :] = in[idx[i], :], zeros for idx < 0  (voxel -> point, PBNet.py:130-134) ----------------------------------
 __global__ __launch_bounds__(256) void k_gather_rows(const uint4* __restrict__ in, const long long* __restrict__ idx,
                                                     int n, int vec_per_row, int ld_in_vec, int ld_out_vec,
                                                     uint4* __restrict__ out) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long long)n * vec_per_row) return;
     const int i = (int)(e / vec_per_row), v = (int)(e % vec_per_row);
-    out[(size_t)i * ld_out_vec + v] = in[(size_t)idx[i] * ld_in_vec + v];
+    const long long r = idx[i];
+    out[(size_t)i * ld_out_vec + v] = r >= 0 ? in[(size_t)r * ld_in_vec + v] : make_uint4(0u, 0u, 0u, 0u);
 }
 
 }  // namespace

@@ -606,6 +606,109 @@ extern "C" int pbn_proposal_rows(const void* mask_score, int ld, float thd, cons
     return PBN_OK;
 }
 
+// ---- rulebook pairs, offset-major (training: operands of the weight gradient) -----------------------------------------
+// pair lists of an output-stationary map nbr[n, K]: for every offset k the (input row, output row) pairs with
+// nbr[o, k] >= 0, output rows ascending, cut into segments of `seg` pairs.  Three launches: per-block column counts,
+// a column-wise exclusive scan over the blocks (+ column totals), the fill.  Positions are prefix counts, never atomics:
+// the lists -- and with them the summation order of the weight gradient -- are the same on every run.
+namespace pbn {
+namespace {
+constexpr int PAIR_ROWS = 256;   // rows per block = TPB
+
+__global__ __launch_bounds__(TPB) void k_pair_count(const int* __restrict__ nbr, int n, int K, int* __restrict__ table) {
+    __shared__ int s_cnt[4];
+    const int row = blockIdx.x * PAIR_ROWS + threadIdx.x;
+    const int wave = threadIdx.x >> 6;
+    for (int k = 0; k < K; ++k) {
+        const bool hit = row < n && nbr[(size_t)row * K + k] >= 0;
+        const int c = __popcll(__ballot(hit));
+        if ((threadIdx.x & 63) == 0) s_cnt[wave] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) table[(size_t)blockIdx.x * K + k] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+}
+
+// one wave per column: table[b][k] <- pairs of column k in blocks before b; totals[k] <- column total
+__global__ __launch_bounds__(64) void k_pair_scan(int* __restrict__ table, int n_blocks, int K, int* __restrict__ totals) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    int run = 0;
+    for (int b0 = 0; b0 < n_blocks; b0 += 64) {
+        const int b = b0 + lane;
+        const int v = b < n_blocks ? table[(size_t)b * K + k] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (b < n_blocks) table[(size_t)b * K + k] = run + inc - v;
+        run += __shfl(inc, 63);
+    }
+    if (lane == 0) totals[k] = run;
+}
+
+__global__ __launch_bounds__(TPB) void k_pair_fill(const int* __restrict__ nbr, int n, int K, const int* __restrict__ table,
+                                                  const int* __restrict__ seg_start, int seg, long long* __restrict__ in_idx,
+                                                  long long* __restrict__ out_idx, long long* __restrict__ seg_offset) {
+    __shared__ int s_cnt[4];
+    const int row = blockIdx.x * PAIR_ROWS + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = 0; k < K; ++k) {
+        const int src = row < n ? nbr[(size_t)row * K + k] : -1;
+        const unsigned long long m = __ballot(src >= 0);
+        if (lane == 0) s_cnt[wave] = __popcll(m);
+        __syncthreads();
+        if (src >= 0) {
+            int pos = table[(size_t)blockIdx.x * K + k] + __popcll(m & ((1ULL << lane) - 1ULL));
+            for (int w = 0; w < wave; ++w) pos += s_cnt[w];
+            const int q = pos / seg;
+            const long long slot = (long long)(seg_start[k] + q) * seg + (pos - q * seg);
+            in_idx[slot] = src;
+            out_idx[slot] = row;
+            if (pos == q * seg) seg_offset[seg_start[k] + q] = k;
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+}  // namespace pbn
+
+extern "C" int pbn_rulebook_pair_blocks(int n) { return n > 0 ? (n + pbn::PAIR_ROWS - 1) / pbn::PAIR_ROWS : 0; }
+
+extern "C" int pbn_rulebook_pair_counts(const int32_t* nbr, int n, int n_offsets, int32_t* table, int32_t* totals,
+                                        pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || n_offsets < 1) return PBN_ERR_ARG;
+    if (!totals) return PBN_ERR_ARG;
+    if (n == 0) { PBN_HIP_CHECK(hipMemsetAsync(totals, 0, sizeof(int32_t) * n_offsets, stream)); return PBN_OK; }
+    if (!nbr || !table) return PBN_ERR_ARG;
+    const int nb = pbn_rulebook_pair_blocks(n);
+    hipLaunchKernelGGL(k_pair_count, dim3(nb), dim3(TPB), 0, stream, nbr, n, n_offsets, table);
+    hipLaunchKernelGGL(k_pair_scan, dim3(n_offsets), dim3(64), 0, stream, table, nb, n_offsets, totals);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_rulebook_pair_fill(const int32_t* nbr, int n, int n_offsets, const int32_t* table, const int32_t* seg_start,
+                                      int seg, int n_segments, int64_t* in_idx, int64_t* out_idx, int64_t* seg_offset,
+                                      pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || n_offsets < 1 || seg < 1 || n_segments < 0) return PBN_ERR_ARG;
+    if (n_segments == 0) return PBN_OK;
+    if (!in_idx || !out_idx || !seg_offset) return PBN_ERR_ARG;
+    // padding slots (and surplus segments) read as -1 / offset 0
+    PBN_HIP_CHECK(hipMemsetAsync(in_idx, 0xff, sizeof(int64_t) * (size_t)n_segments * seg, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(out_idx, 0xff, sizeof(int64_t) * (size_t)n_segments * seg, stream));
+    PBN_HIP_CHECK(hipMemsetAsync(seg_offset, 0, sizeof(int64_t) * (size_t)n_segments, stream));
+    if (n == 0) return PBN_OK;
+    if (!nbr || !table || !seg_start) return PBN_ERR_ARG;
+    hipLaunchKernelGGL(k_pair_fill, dim3(pbn_rulebook_pair_blocks(n)), dim3(TPB), 0, stream, nbr, n, n_offsets, table, seg_start,
+                       seg, (long long*)in_idx, (long long*)out_idx, (long long*)seg_offset);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
 extern "C" int pbn_gather_rulebook_rows(const void* in, int ld_in_bytes, int row_bytes, const int32_t* nbr, int n_offsets,
                                         int k0, int kc, int n, void* out, pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;

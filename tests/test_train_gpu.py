@@ -147,3 +147,28 @@ def test_pbnet_training_step_runs():
     for prefix in ("D_Unet.", "score_Unet.", "linear_binary.", "linear_IOU.", "MEUnet."):
         assert any(g.startswith(prefix) for g in got), prefix
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_rulebook_pairs_against_nonzero():
+    """pbn_rulebook_pair_* (offset-major pair lists of the weight gradient) against torch.nonzero on random maps: same
+    pairs in the same order inside every offset, padding = -1, segment -> offset table, surplus-free segment count."""
+    from pbnet_amd.MinkowskiEngine.conv import rulebook_pairs
+    g = torch.Generator().manual_seed(3)
+    for v, k, density, seg in ((1000, 27, 0.3, 64), (70001, 27, 0.26, 4096), (333, 8, 0.12, 16), (5000, 125, 0.15, 512),
+                               (257, 1, 1.0, 100), (40, 27, 0.0, 8)):
+        nbr = torch.where(torch.rand(v, k, generator=g) < density, torch.randint(0, v, (v, k), generator=g),
+                          torch.full((v, k), -1)).to(torch.int32).to(DEV)
+        in_idx, out_idx, seg_offset, n_seg = rulebook_pairs(nbr, seg)
+        cnt = (nbr >= 0).sum(0).cpu()
+        assert n_seg == int(((cnt + seg - 1) // seg).sum()) and in_idx.shape[0] == n_seg * seg == out_idx.shape[0]
+        kv = (nbr >= 0).t().nonzero().cpu()                               # offset-major, output rows ascending
+        want_in = nbr.cpu()[kv[:, 1], kv[:, 0]].long()
+        valid = (in_idx >= 0).cpu()
+        assert torch.equal(valid, (out_idx >= 0).cpu()) and int(valid.sum()) == kv.shape[0]
+        assert torch.equal(in_idx.cpu()[valid], want_in) and torch.equal(out_idx.cpu()[valid], kv[:, 1])
+        seg_of_slot = torch.arange(n_seg * seg) // seg
+        assert torch.equal(seg_offset.cpu()[seg_of_slot[valid]], kv[:, 0])
+        # padding only at the tail of an offset's last segment
+        per_seg = valid.view(n_seg, seg).sum(1) if n_seg else valid.sum()
+        if n_seg:
+            assert ((per_seg > 0).all()) and (valid.view(n_seg, seg).long().diff(dim=1) <= 0).all()
