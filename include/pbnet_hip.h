@@ -212,6 +212,22 @@ int pbn_pack_weight(const float* src, int n_offsets, int dim_a, int dim_b, int f
 int pbn_gather_rulebook_rows(const void* in, int ld_in_bytes, int row_bytes, const int32_t* nbr, int n_offsets, int k0,
                              int kc, int n, void* out, pbn_stream_t stream);
 
+/* Train-mode batch normalisation of a feature slab x[n, channels] (row stride ld_* elements, rows 16-byte aligned;
+ * ME.MinkowskiBatchNorm = torch.nn.BatchNorm1d on .F, /root/reference/network/Mink.py:71-73,224; training, configs[2]).
+ *   forward : save_mean / save_invstd f32[channels] from the batch (biased variance), running_mean / running_var (NULL =
+ *             not tracked) updated with `momentum` and the unbiased variance, y = (x - mean) * invstd * weight + bias
+ *             (weight / bias NULL = 1 / 0).  fp32 arithmetic, sums merged in a fixed order (double for the final merge).
+ *   backward: dx, dweight = sum dy * xhat, dbias = sum dy (either may be NULL).
+ * workspace: pbn_bn_workspace_bytes(channels).  PBN_ERR_UNSUPPORTED when channels is not a multiple of the 16-byte
+ * vector width of `dtype` or a row is not 16-byte aligned (the caller then uses the framework's batch norm). */
+size_t pbn_bn_workspace_bytes(int channels);
+int pbn_bn_train_forward(const void* x, int ld_x, int n, int channels, int dtype, const float* weight, const float* bias,
+                         float eps, float momentum, float* running_mean, float* running_var, void* y, int ld_y,
+                         float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, pbn_stream_t stream);
+int pbn_bn_train_backward(const void* x, int ld_x, const void* dy, int ld_dy, int n, int channels, int dtype,
+                          const float* weight, const float* save_mean, const float* save_invstd, void* dx, int ld_dx,
+                          float* dweight, float* dbias, void* workspace, size_t workspace_bytes, pbn_stream_t stream);
+
 /* Offset-major pair lists of an output-stationary map (training, BASELINE configs[2]): the rule pairs of ME's
  * convolution weight gradient, dW[k] = sum over pairs (i, o) of offset k of x[i]^T g[o].
  *   pbn_rulebook_pair_counts : table int32[pbn_rulebook_pair_blocks(n), K] (per-block prefix counts, kept for the fill)

@@ -6,8 +6,72 @@ import torch.nn as nn
 from .core import SparseTensor
 
 
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+_BN_WS = {}
+
+
+def _bn_workspace(device, channels):
+    """Per (device, stream) scratch of the native batch norm (block partial sums), grown on demand."""
+    from .. import _native as N
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    need = int(N.lib().pbn_bn_workspace_bytes(int(channels)))
+    ws = _BN_WS.get(key)
+    if ws is None or ws.numel() < need:
+        while len(_BN_WS) >= 16:
+            _BN_WS.pop(next(iter(_BN_WS)))
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _BN_WS[key] = ws
+    return ws
+
+
+def _rows_ok(t):
+    es = t.element_size()
+    return t.dim() == 2 and t.stride(1) == 1 and (t.stride(0) * es) % 16 == 0 and t.data_ptr() % 16 == 0 \
+        and (t.shape[1] * es) % 16 == 0 and t.shape[0] > 0
+
+
+class _BatchNormTrainFn(torch.autograd.Function):
+    """Train-mode nn.BatchNorm1d on a feature slab through pbn_bn_train_forward / _backward (csrc/bnorm.hip): same
+    statistics (biased variance to normalise, unbiased into running_var), fp32 arithmetic on f32 / bf16 / f16 slabs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+        from .. import _native as N
+        n, c = int(x.shape[0]), int(x.shape[1])
+        y = torch.empty(n, c, dtype=x.dtype, device=x.device)
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = _bn_workspace(x.device, c)
+        N.check(N.lib().pbn_bn_train_forward(N.c_vp(x.data_ptr()), x.stride(0), n, c, _DT[x.dtype], N.ptr(weight), N.ptr(bias),
+                                             float(eps), float(momentum), N.ptr(running_mean), N.ptr(running_var),
+                                             N.c_vp(y.data_ptr()), c, N.ptr(mean), N.ptr(invstd), N.c_vp(ws.data_ptr()),
+                                             ws.numel(), N.current_stream()), "pbn_bn_train_forward")
+        ctx.save_for_backward(x, weight, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _native as N
+        x, weight, mean, invstd = ctx.saved_tensors
+        n, c = int(x.shape[0]), int(x.shape[1])
+        if dy.dtype != x.dtype or not _rows_ok(dy):
+            dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty(n, c, dtype=x.dtype, device=x.device)
+        need_w = weight is not None and ctx.needs_input_grad[1]
+        dw = torch.empty(c, dtype=torch.float32, device=x.device) if need_w else None
+        db = torch.empty(c, dtype=torch.float32, device=x.device) if (weight is not None and ctx.needs_input_grad[2]) else None
+        ws = _bn_workspace(x.device, c)
+        N.check(N.lib().pbn_bn_train_backward(N.c_vp(x.data_ptr()), x.stride(0), N.c_vp(dy.data_ptr()), dy.stride(0), n, c,
+                                              _DT[x.dtype], N.ptr(weight), N.ptr(mean), N.ptr(invstd), N.c_vp(dx.data_ptr()), c,
+                                              N.ptr(dw), N.ptr(db), N.c_vp(ws.data_ptr()), ws.numel(), N.current_stream()),
+                "pbn_bn_train_backward")
+        return dx, dw, db, None, None, None, None
+
+
 class MinkowskiBatchNorm(nn.Module):
     """ME.MinkowskiBatchNorm: `self.bn = nn.BatchNorm1d` on .F (Mink.py:71-73 reaches into `.bn`)."""
+
+    NATIVE_TRAIN = True          # train-mode statistics / normalisation / gradients through csrc/bnorm.hip
 
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
         super().__init__()
@@ -15,9 +79,16 @@ class MinkowskiBatchNorm(nn.Module):
                                  track_running_stats=track_running_stats)
 
     def forward(self, x):
+        f, bn = x.F, self.bn
+        if self.NATIVE_TRAIN and bn.training and f.is_cuda and bn.momentum is not None and f.dtype in _DT and _rows_ok(f) \
+                and (bn.weight is None or bn.weight.dtype == torch.float32):
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+            return x.replace_feature(_BatchNormTrainFn.apply(f, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum))
         # torch's batch-norm kernels take bf16/f16 slabs with fp32 parameters and statistics directly (identical
         # output to an fp32 round trip, two conversion launches fewer in each direction)
-        return x.replace_feature(self.bn(x.F))
+        return x.replace_feature(bn(f))
 
 
 class _Elementwise(nn.Module):

@@ -95,6 +95,11 @@ SIGNATURES = {
     "pbn_bitmask_to_dense": (c_int, [c_vp, c_i32p, c_int, c_int, c_i32p, c_vp]),
     "pbn_instance_overlap": (c_int, [c_i32p, c_int, c_int, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_rulebook_pair_blocks": (c_int, [c_int]),
+    "pbn_bn_workspace_bytes": (c_size, [c_int]),
+    "pbn_bn_train_forward": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_f32p, c_f32p, ctypes.c_float, ctypes.c_float, c_f32p,
+                                     c_f32p, c_vp, c_int, c_f32p, c_f32p, c_vp, c_size, c_vp]),
+    "pbn_bn_train_backward": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_vp, c_int,
+                                      c_f32p, c_f32p, c_vp, c_size, c_vp]),
     "pbn_rulebook_pair_counts": (c_int, [c_i32p, c_int, c_int, c_i32p, c_i32p, c_vp]),
     "pbn_rulebook_pair_fill": (c_int, [c_i32p, c_int, c_int, c_i32p, c_i32p, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "pbn_gather_rulebook_rows": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_vp]),

@@ -172,3 +172,42 @@ def test_rulebook_pairs_against_nonzero():
         per_seg = valid.view(n_seg, seg).sum(1) if n_seg else valid.sum()
         if n_seg:
             assert ((per_seg > 0).all()) and (valid.view(n_seg, seg).long().diff(dim=1) <= 0).all()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_native_batch_norm_matches_torch(dtype, tol):
+    """csrc/bnorm.hip (train-mode statistics, normalisation, gradients) against torch.nn.BatchNorm1d on the same slab:
+    outputs, running statistics (unbiased variance), dx / dweight / dbias; channel means far from zero."""
+    import pbnet_amd.MinkowskiEngine as ME
+    from pbnet_amd.MinkowskiEngine.nn import MinkowskiBatchNorm
+    g = torch.Generator().manual_seed(7)
+    for n, c in ((1000, 32), (146001, 96), (77, 256), (5, 384), (4097, 64), (1, 32)):
+        x0 = (torch.randn(n, c, generator=g) * (torch.rand(c, generator=g) * 3 + 0.1) + torch.randn(c, generator=g) * 5).to(DEV)
+        gy = torch.randn(n, c, generator=g).to(DEV)
+        outs = []
+        for native in (True, False):
+            m = MinkowskiBatchNorm(c).to(DEV).train()
+            with torch.no_grad():
+                m.bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+                m.bn.bias.copy_(torch.linspace(-1, 1, c))
+            m.NATIVE_TRAIN = native
+            x = x0.to(dtype).requires_grad_(True)
+            i = torch.arange(n, dtype=torch.int32)
+            coords = torch.stack([torch.zeros_like(i), i % 1000, i // 1000, torch.zeros_like(i)], 1).to(DEV)
+            if n == 1 and not native:
+                outs.append(None)                       # torch refuses one value per channel in training mode
+                continue
+            y = m(ME.SparseTensor(x, coords)).F
+            y.backward(gy.to(dtype))
+            outs.append((y.detach().float(), x.grad.float(), m.bn.weight.grad.clone(), m.bn.bias.grad.clone(),
+                         m.bn.running_mean.clone(), m.bn.running_var.clone(), int(m.bn.num_batches_tracked)))
+        if outs[1] is None:
+            assert torch.isfinite(outs[0][0]).all()
+            continue
+        for k, (a, b) in enumerate(zip(outs[0], outs[1])):
+            if k == 6:
+                assert a == b == 1
+                continue
+            scale = max(1.0, float(b.abs().max()))
+            t = tol if k < 2 else max(2e-5, tol * 1e-1) * (n if k in (2, 3) else 1) ** 0.5   # sums over n rows
+            assert float((a - b).abs().max()) <= t * scale, (n, c, k, float((a - b).abs().max()), scale)
