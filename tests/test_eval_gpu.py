@@ -139,3 +139,41 @@ def test_edge_cases(tmp_path):
                                                 mask=np.ones((1, 500), np.int32)), none, device=DEV)
     assert rec.gt_id.shape[0] == 0 and list(rec.pred_void) == [500]
     assert np.isnan(E.evaluate_matches([rec])).all()
+
+
+def test_ground_truth_as_prediction_scores_one():
+    """Whole evaluator chain on a bench-sized synthetic scene: ids from (semantic, instance) labels (get_val_gt.py
+    encoding), the ground-truth instances themselves as predictions -> AP 1 at every threshold for every class present,
+    nan elsewhere; the same masks cut to their first half (IoU exactly 1/2) fail the strict `> 0.5` test but pass 0.25."""
+    from pbnet_amd import synth
+    batch, teacher, _ = synth.make_val_batch(seed=2, copies=1)
+    ins = batch["ins"].astype(np.int64)
+    sem = teacher["sem_score"].argmax(1).astype(np.int64)
+    for i in np.unique(ins[ins >= 0]):                       # one class per instance, as in a real scan
+        sem[ins == i] = sem[np.nonzero(ins == i)[0][0]]
+    gt = E.encode_gt_ids(sem, ins)
+    assert np.array_equal(gt, O.encode_gt_ids(sem, ins))
+    ids = [int(i) for i in np.unique(gt) if i >= 1000 and (i // 1000) in E.VALID_CLASS_IDS]
+    big = [i for i in ids if (gt == i).sum() >= E.MIN_REGION_SIZE]
+    assert len(big) >= 5
+    masks = np.stack([(gt == i).astype(np.int32) for i in ids])
+    pred = dict(conf=np.linspace(0.9, 0.5, len(ids)).astype(np.float32), label_id=np.array([i // 1000 for i in ids]),
+                mask=torch.from_numpy(masks).to(DEV))
+    ap = E.evaluate_matches({"s": E.assign_instances_for_scan("s", pred, gt)})
+    present = sorted({E._CLASS_OF_ID[i // 1000] for i in big})
+    for li in range(len(E.CLASS_LABELS)):
+        if li in present:
+            assert (ap[0, li] == 1.0).all(), li
+        else:
+            assert np.isnan(ap[0, li]).all(), li
+    avgs = E.compute_averages(ap)
+    assert avgs["all_ap"] == avgs["all_ap_50%"] == avgs["all_ap_25%"] == 1.0
+    half = masks.copy()
+    for r, i in enumerate(ids):
+        pts = np.nonzero(gt == i)[0]
+        half[r, pts[len(pts) // 2:]] = 0                      # keeps floor(n/2) points: IoU <= 1/2
+    ap2 = E.evaluate_matches({"s": E.assign_instances_for_scan("s", dict(pred, mask=half), gt, device=DEV)})
+    o25 = int(np.argmin(np.abs(E.OVERLAPS - 0.25)))
+    kept = [li for li in present if any((gt == i).sum() // 2 >= E.MIN_REGION_SIZE for i in big if E._CLASS_OF_ID[i // 1000] == li)]
+    for li in kept:
+        assert ap2[0, li, 0] == 0.0 and ap2[0, li, o25] > 0.0, li
