@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native as N
+from ..scratch import StreamScratch
 from .core import SparseTensor
 
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
@@ -85,21 +86,14 @@ class _PackCache(object):
         return hit[1]
 
 
-_WS = {}
 SPLITK_WORKSPACE_BYTES = 256 << 20
+_WS = StreamScratch()
 
 
 def _workspace(device):
-    """Scratch for split-K launches (fp32 partial slabs), allocated once per (device, stream): launches on one stream
-    are ordered, two scenes in flight on two streams must not share the slabs."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _WS.get(key)
-    if ws is None:
-        while len(_WS) >= 16:               # streams come and go in a serving loop: drop the oldest entry (its block goes
-            _WS.pop(next(iter(_WS)))        # back to the pool of the stream it was allocated on, which orders any reuse)
-        ws = torch.empty(SPLITK_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
-        _WS[key] = ws
-    return ws
+    """Scratch for split-K launches (fp32 partial slabs), one block per (device, stream): launches on one stream are
+    ordered, two scenes in flight on two streams must not share the slabs."""
+    return _WS.get(device, SPLITK_WORKSPACE_BYTES)
 
 
 def spconv_forward(feats, nbr, n_out, packed, scale=None, shift=None, residual=None, relu=False, out=None,

@@ -3,25 +3,18 @@ thin wrappers that apply a torch module to the feature matrix, exactly as Minkow
 import torch
 import torch.nn as nn
 
+from ..scratch import StreamScratch
 from .core import SparseTensor
 
 
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
-_BN_WS = {}
+_BN_WS = StreamScratch()
 
 
 def _bn_workspace(device, channels):
     """Per (device, stream) scratch of the native batch norm (block partial sums), grown on demand."""
     from .. import _native as N
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    need = int(N.lib().pbn_bn_workspace_bytes(int(channels)))
-    ws = _BN_WS.get(key)
-    if ws is None or ws.numel() < need:
-        while len(_BN_WS) >= 16:
-            _BN_WS.pop(next(iter(_BN_WS)))
-        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
-        _BN_WS[key] = ws
-    return ws
+    return _BN_WS.get(device, int(N.lib().pbn_bn_workspace_bytes(int(channels))), min_bytes=1 << 20)
 
 
 def _rows_ok(t):

@@ -1,7 +1,9 @@
 """One process per GPU.  Inference shards SCENES (independent units: /root/reference/eval_map.py:48-50 handles one
 scene at a time) with no data-path collective; training adds exactly one exchange step per iteration, the gradient
-all-reduce of /root/reference/train.py:345 (DDP), here as flat fp32 buckets sized for RCCL over xGMI.
-SyncBatchNorm (train.py:343-344) is deliberately not reproduced (BASELINE.json north_star: "gradients only")."""
+all-reduce of /root/reference/train.py:345 (DDP), here as flat buckets sized for RCCL over xGMI and issued from
+gradient hooks so that the ring overlaps backward (GradientReducer).  SyncBatchNorm (train.py:343-344) is deliberately
+not reproduced (BASELINE.json north_star: "gradients only"); sync_buffers() makes the BatchNorm statistics of all ranks
+equal before validation / checkpointing."""
 import torch
 import torch.distributed as dist
 
@@ -40,32 +42,144 @@ def gather_scene_results(local, dst=0):
     return merged
 
 
-def allreduce_gradients(params, bucket_bytes=64 << 20):
-    """Average gradients across ranks in flat buckets (>= 64 MB keeps a ring on 7 x 153 GB/s xGMI links bandwidth-
-    rather than latency-bound).  Parameters without a gradient on this rank (the mask/score
-    branches while epoch <= cluster_epoch, train.py:345 find_unused_parameters=True) contribute zeros."""
-    if not (dist.is_available() and dist.is_initialized()):
+class GradientReducer(object):
+    """The one exchange step of training (/root/reference/train.py:345, DistributedDataParallel with
+    find_unused_parameters=True), re-designed for RCCL over xGMI rather than translated:
+
+      * parameters are cut into flat buckets in REVERSE registration order (the order backward produces gradients);
+        a bucket's all-reduce is issued asynchronously from the post-accumulate hook of its last gradient, so the ring
+        runs beside the rest of backward (on `nccl` = RCCL the collective runs on the process group's own stream);
+      * buckets are >= 64 MB by default: xGMI is point to point (7 links x ~153 GB/s per GPU), a ring step is per-link
+        bound, and few large messages keep it bandwidth- rather than latency-bound (84 M parameters: 336 MB fp32,
+        168 MB with comm_dtype=torch.bfloat16);
+      * a parameter that received no gradient on ANY rank keeps grad None, exactly like DDP with
+        find_unused_parameters=True (the mask / score branches while epoch <= cluster_epoch): a per-parameter `used`
+        flag travels with a MAX reduction, so Adam creates no state and applies no decay for untrained weights; a
+        parameter unused on this rank but used elsewhere contributes zeros.
+
+    Usage:  r = GradientReducer(model.parameters());  loss.backward();  r.finish();  optimizer.step()"""
+
+    def __init__(self, params, bucket_bytes=64 << 20, comm_dtype=torch.float32, overlap=True):
+        self.params = [p for p in params if p.requires_grad]
+        self.comm_dtype = comm_dtype
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        esz = torch.empty(0, dtype=comm_dtype).element_size()
+        self.buckets = []                       # each: dict(params, offsets, flat, pending, work)
+        cur, size = [], 0
+        for p in reversed(self.params):
+            if cur and size + p.numel() * esz > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += p.numel() * esz
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {}
+        packed = []
+        for bi, plist in enumerate(self.buckets):
+            offs, off = [], 0
+            for p in plist:
+                offs.append(off)
+                off += p.numel()
+                self._bucket_of[id(p)] = (bi, len(offs) - 1)
+            packed.append(dict(params=plist, offsets=offs, numel=off, flat=None, pending=len(plist), work=None,
+                               filled=[False] * len(plist)))
+        self.buckets = packed
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._next = 0                          # next bucket index to go on the wire
+        self._hooks = []
+        if overlap and self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    # ---- per-gradient path (called by autograd during backward) ----------------------------------------------------
+    def _flat(self, b, like):
+        if b["flat"] is None or b["flat"].device != like.device:
+            b["flat"] = torch.zeros(b["numel"], dtype=self.comm_dtype, device=like.device)
+        return b["flat"]
+
+    def _on_grad(self, p):
+        bi, pi = self._bucket_of[id(p)]
+        b = self.buckets[bi]
+        if b["filled"][pi]:                      # a second backward before finish(): the hook sees the accumulated grad
+            return
+        flat = self._flat(b, p)
+        flat[b["offsets"][pi]:b["offsets"][pi] + p.numel()].copy_(p.grad.detach().reshape(-1))
+        b["filled"][pi] = True
+        b["pending"] -= 1
+        # every rank must issue the same collectives in the same order: buckets go out strictly by index (a bucket
+        # that completes early waits for its predecessors; what backward never completes is issued by finish())
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            nb = self.buckets[self._next]
+            nb["work"] = dist.all_reduce(nb["flat"], op=dist.ReduceOp.SUM, async_op=True)
+            self._next += 1
+
+    # ---- after backward -------------------------------------------------------------------------------------------
+    def finish(self):
+        """Issue what backward did not, wait, write the averaged gradients back.  Returns the number of buckets."""
+        if self.world == 1:
+            return 0
+        dev = next((p.grad.device for p in self.params if p.grad is not None), self.params[0].device)
+        used = torch.tensor([1 if p.grad is not None else 0 for p in self.params], dtype=torch.int32, device=dev)
+        for b in self.buckets[self._next:]:
+            flat = self._flat(b, self.params[0] if dev is None else torch.empty(0, device=dev))
+            for pi, p in enumerate(b["params"]):
+                if b["filled"][pi]:
+                    continue
+                sl = flat[b["offsets"][pi]:b["offsets"][pi] + p.numel()]
+                if p.grad is not None:           # gradients produced without the hook path (overlap=False)
+                    sl.copy_(p.grad.detach().reshape(-1))
+                else:
+                    sl.zero_()
+            b["work"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        used_work = dist.all_reduce(used, op=dist.ReduceOp.MAX, async_op=True)
+        self._next = 0
+        used_work.wait()
+        used_h = used.cpu().tolist()
+        for b in self.buckets:
+            b["work"].wait()
+            flat = b["flat"]
+            for pi, p in enumerate(b["params"]):
+                if not used_h[self._index[id(p)]]:
+                    p.grad = None                # unused on every rank: the optimiser must skip it (DDP semantics)
+                    continue
+                g = flat[b["offsets"][pi]:b["offsets"][pi] + p.numel()].view_as(p)
+                if p.grad is None:
+                    p.grad = (g / self.world).to(p.dtype)
+                else:
+                    p.grad.copy_(g / self.world)
+            b["work"], b["pending"], b["filled"] = None, len(b["params"]), [False] * len(b["params"])
+        return len(self.buckets)
+
+
+def allreduce_gradients(params, bucket_bytes=64 << 20, comm_dtype=torch.float32):
+    """Post-backward form (no overlap): average the gradients of `params` across ranks in flat buckets.  Parameters
+    without a gradient on any rank keep grad None; see GradientReducer."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
-    world = dist.get_world_size()
-    params = [p for p in params if p.requires_grad]
-    n_buckets, i = 0, 0
-    while i < len(params):
-        bucket, size = [], 0
-        while i < len(params) and (not bucket or size + params[i].numel() * 4 <= bucket_bytes):
-            bucket.append(params[i])
-            size += params[i].numel() * 4
-            i += 1
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().float().reshape(-1)
-                          for p in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat /= world
+    return GradientReducer(params, bucket_bytes=bucket_bytes, comm_dtype=comm_dtype, overlap=False).finish()
+
+
+def sync_buffers(module, src=0):
+    """SyncBatchNorm is deliberately not reproduced (north_star: "gradients only"), so BatchNorm running statistics
+    drift per rank; DDP would broadcast rank 0's buffers every iteration (broadcast_buffers=True, train.py:345).  Call
+    this before validation and before checkpoint_save so that every rank evaluates -- and the file holds -- ONE model:
+    rank `src`'s buffers, in one flat broadcast per dtype."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    groups = {}
+    for b in module.buffers():
+        groups.setdefault((b.dtype, b.device), []).append(b)
+    for (_, _), bufs in sorted(groups.items(), key=lambda kv: str(kv[0])):
+        flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+        dist.broadcast(flat, src=src)
         off = 0
-        for p in bucket:
-            g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += p.numel()
-        n_buckets += 1
-    return n_buckets
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+    return sum(len(v) for v in groups.values())

@@ -432,17 +432,15 @@ class PBNet(nn.Module):
         return proposals_idx.detach(), proposals_offset.to(dev), cluster_id_v.to(dev), proposals_ms
 
 
-def model_fn(batch, model, epoch, cfg, task="train"):
-    """PBNet.py:349-444: forward + losses.  Losses are plain torch on the device (outside the kernel scope)."""
-    from .. import pbnet_ops as ops
-    xyz_original = batch["xyz_original"].cuda()
-    ins_label = batch["ins"].cuda()
-    ret = model(batch["feat_voxel"], batch["xyz_voxel"], xyz_original, batch["v2p_index"], ins_label, epoch, task)
-    sem_label = batch["sem"].cuda()
-    instance_info = batch["inst_info"].cuda()
-    instance_pointnum = batch["instance_pointnum"].cuda()
-    sem_pred_score_p, offset_pred_p, sem_pred_p = ret["sem_pred_score_p"].float(), ret["offset_pred_p"].float(), ret["sem_pred_p"]
+def model_losses(ret, sem_label, ins_label, instance_info, instance_pointnum, xyz_original, epoch, cfg, get_iou=None):
+    """The loss arithmetic of model_fn (PBNet.py:366-416) on tensors that are already on one device.  Returns
+    (loss, parts, valid, mask_label_weight, gt_mask_out): `parts` holds every term as a tensor.
 
+    Reference quirk kept on purpose (PBNet.py:398-405): `gt_mask[gt_mask == -1.] = 0.5` runs IN PLACE on a LONG
+    tensor, so the ignore rows become 0 (0.5 truncates); the later `gt_mask != -1` is therefore all-true: the dice
+    term covers EVERY row with the ignore rows as target 0, the BCE term masks them out through its weight, and the
+    mutated gt_mask is what pred['mask_scores'] returns."""
+    sem_pred_score_p, offset_pred_p = ret["sem_pred_score_p"].float(), ret["offset_pred_p"].float()
     semantic_loss = nn.CrossEntropyLoss(ignore_index=-100)(sem_pred_score_p, sem_label)
     gt_offsets = instance_info[:, 0:3] - xyz_original
     pt_dist = torch.sum(torch.abs(offset_pred_p - gt_offsets), dim=-1)
@@ -452,33 +450,49 @@ def model_fn(batch, model, epoch, cfg, task="train"):
     pt_dir = offset_pred_p / (torch.norm(offset_pred_p, p=2, dim=1).unsqueeze(-1) + 1e-8)
     offset_dir_loss = torch.sum(-(gt_dir * pt_dir).sum(-1) * valid) / (torch.sum(valid) + 1e-6)
     loss = semantic_loss + offset_norm_loss + offset_dir_loss
-
+    parts = {"semantic_loss": semantic_loss, "offset_norm_loss": offset_norm_loss, "offset_dir_loss": offset_dir_loss}
+    weight = gt_mask = None
     if epoch > cfg.cluster_epoch:
         pred_mask, gt_mask = ret["mask_scores"]
         pred_mask = pred_mask.float()
         weight = (gt_mask != -1).float()
-        target = gt_mask.float().clone()
-        target[gt_mask == -1] = 0.5
-        mask_loss = nn.BCELoss(reduction="none", weight=weight)(pred_mask.view(-1), target).mean()
-        loss = loss + mask_loss
-        sel = gt_mask != -1
-        loss = loss + diceLoss(pred_mask.view(-1)[sel], gt_mask[sel].float())
+        gt_mask[gt_mask == -1] = 0                                 # the reference's `= 0.5` on a long tensor
+        mask_loss = nn.BCELoss(reduction="none", weight=weight)(pred_mask.view(-1), gt_mask.float()).mean()
+        dice_loss = diceLoss(pred_mask.view(-1), gt_mask.view(-1))   # every row (see the docstring)
         proposals_idx, proposals_offset, _, _ = ret["proposals"]
-        ious = ops.get_iou(proposals_idx[:, 1].contiguous().cuda(), proposals_offset.cuda(), ins_label, instance_pointnum)
+        if get_iou is None:
+            from .. import pbnet_ops as ops
+            get_iou = ops.get_iou
+        ious = get_iou(proposals_idx[:, 1].contiguous(), proposals_offset, ins_label, instance_pointnum)
         gt_ious, _ = ious.max(1)
         gt_scores = get_segmented_scores(gt_ious, cfg.fg_thresh, cfg.bg_thresh)
         score_loss = nn.BCELoss()(ret["clt_scores"].float().view(-1), gt_scores).mean()
-        loss = loss + score_loss
+        loss = loss + mask_loss + dice_loss + score_loss
+        parts.update(mask_loss=mask_loss, dice_loss=dice_loss, score_loss=score_loss)
+    parts["loss"] = loss
+    return loss, parts, valid, weight, gt_mask
 
+
+def model_fn(batch, model, epoch, cfg, task="train"):
+    """PBNet.py:349-444: forward + losses.  Losses are plain torch on the device (outside the kernel scope); their
+    arithmetic is restated independently in oracle/loss_ref.py and compared in tests/test_losses.py."""
+    xyz_original = batch["xyz_original"].cuda()
+    ins_label = batch["ins"].cuda()
+    ret = model(batch["feat_voxel"], batch["xyz_voxel"], xyz_original, batch["v2p_index"], ins_label, epoch, task)
+    sem_label = batch["sem"].cuda()
+    instance_info = batch["inst_info"].cuda()
+    instance_pointnum = batch["instance_pointnum"].cuda()
+    offset_pred_p, sem_pred_p = ret["offset_pred_p"].float(), ret["sem_pred_p"]
+    loss, parts, valid, weight, gt_mask = model_losses(ret, sem_label, ins_label, instance_info, instance_pointnum,
+                                                       xyz_original.float(), epoch, cfg)
     with torch.no_grad():
         pred = {"sem": sem_pred_p, "offseted_xyz": xyz_original + offset_pred_p}
-        visual_dict = {"loss": loss.item(), "semantic_loss": semantic_loss.item(),
-                       "offset_norm_loss": offset_norm_loss.item(), "offset_dir_loss": offset_dir_loss.item()}
+        visual_dict = {k: parts[k].item() for k in ("loss", "semantic_loss", "offset_norm_loss", "offset_dir_loss")}
         meter_dict = {k: (v, valid.sum()) for k, v in visual_dict.items()}
         if epoch > cfg.cluster_epoch:
-            visual_dict["mask_loss"] = mask_loss.item()
-            meter_dict["mask_loss"] = (mask_loss.item(), weight.sum())
-            pred["mask_scores"] = ret["mask_scores"]
+            visual_dict["mask_loss"] = parts["mask_loss"].item()
+            meter_dict["mask_loss"] = (visual_dict["mask_loss"], weight.sum())
+            pred["mask_scores"] = ret["mask_scores"]               # carries the mutated gt_mask, as upstream
             pred["proposals"] = ret["proposals"]
             pred["clt_scores"] = ret["clt_scores"]
     return loss, pred, visual_dict, meter_dict

@@ -1,0 +1,29 @@
+"""Per-(device, stream) scratch blocks shared by the host-side wrappers (split-K slabs, batch-norm partials).
+Scenes in flight run on several host threads, so the table is guarded by a lock and evicts least-recently-used."""
+import threading
+from collections import OrderedDict
+
+import torch
+
+
+class StreamScratch(object):
+    def __init__(self, max_entries=16):
+        self._lock = threading.Lock()
+        self._table = OrderedDict()
+        self._max = max_entries
+
+    def get(self, device, nbytes, min_bytes=0):
+        """A uint8 block of at least `nbytes` owned by (device, current stream); grown on demand."""
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        with self._lock:
+            ws = self._table.get(key)
+            if ws is not None and ws.numel() >= nbytes:
+                self._table.move_to_end(key)
+                return ws
+            # an evicted block goes back to the pool of the stream it was allocated on, which orders any reuse
+            while len(self._table) >= self._max and key not in self._table:
+                self._table.popitem(last=False)
+            ws = torch.empty(max(int(nbytes), int(min_bytes)), dtype=torch.uint8, device=device)
+            self._table[key] = ws
+            self._table.move_to_end(key)
+            return ws

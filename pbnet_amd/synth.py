@@ -135,3 +135,27 @@ def make_val_batch(seed=2, copies=1, room=(4.0, 3.2, 2.6), n_boxes=12, pitch=0.0
     teacher = dict(sem_score=score, offset=np.concatenate(off_l))
     info = dict(n_points=int(len(sem)), n_voxels=int(nv), copies=copies, seed=seed)
     return batch, teacher, info
+
+
+def make_train_batch(seed=10, copies=1, **kw):
+    """A train-style batch dict as dataset_preprocess.trainMerge builds it (:178-305): make_val_batch's geometry plus
+    the label tensors model_fn reads (PBNet.py:359-363): `sem` i64[N] (-100 = ignore), `inst_info` f32[N,9] (instance
+    mean xyz in columns 0:3, dataset_preprocess.py:121-147), `instance_pointnum` i32[I].  Semantic labels are the
+    teacher's arg-max (so the semantic loss has a non-trivial value); floor / walls carry instance -100."""
+    batch, teacher, info = make_val_batch(seed=seed, copies=copies, **kw)
+    n = batch["xyz_original"].shape[0]
+    ins = batch["ins"]
+    n_inst = int(ins.max()) + 1 if (ins >= 0).any() else 0
+    inst_info = np.zeros((n, 9), np.float32)
+    pointnum = np.zeros(n_inst, np.int32)
+    for i in range(n_inst):
+        m = ins == i
+        pointnum[i] = int(m.sum())
+        if pointnum[i]:
+            pts = batch["xyz_original"][m]
+            inst_info[m, 0:3] = pts.mean(0)
+            inst_info[m, 3:6] = pts.min(0)
+            inst_info[m, 6:9] = pts.max(0)
+    batch = dict(batch, sem=teacher["sem_score"].argmax(1).astype(np.int64), inst_info=inst_info,
+                 instance_pointnum=pointnum)
+    return batch, teacher, info

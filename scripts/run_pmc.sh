@@ -2,7 +2,10 @@
 # two rocprofv3 --pmc passes over the default bench command (separate runs, no trace domains), summarised into
 # profiles/r01_pmc_summary.json by scripts/summarize_pmc.py
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT unset)}
+# bench.py sets this with os.environ.setdefault, but under rocprofv3 the profiler has initialised the runtime before
+# Python starts: export it in the shell so that the profiled run uses the same 8 hardware queues as the plain run
+export GPU_MAX_HW_QUEUES=8
 cd $R
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pmc_$c

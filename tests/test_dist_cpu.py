@@ -22,20 +22,59 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
-    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2))
+
+    def make():
+        torch.manual_seed(0)
+        return torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2),
+                                   torch.nn.BatchNorm1d(4))
     x = torch.full((3, 8), float(rank + 1))
-    net[1](net[0](x)).sum().backward()            # net[2] gets no gradient (unused branch)
+    # (1) post-backward form; net[2] is unused on every rank, net[1] only on rank 1 (contributes zeros there)
+    net = make()
+    h = net[0](x)
+    (net[1](h).sum() if rank == 0 else h.sum()).backward()
     local = [p.grad.clone() if p.grad is not None else None for p in net.parameters()]
     nb = pd.allreduce_gradients(net.parameters(), bucket_bytes=256)
     gathered = [None] * world
     dist.all_gather_object(gathered, [g.tolist() if g is not None else None for g in local])
     ok = nb > 1
+    names = [n for n, _ in net.named_parameters()]
     for i, p in enumerate(net.parameters()):
-        if gathered[0][i] is None:
-            ok = ok and float(p.grad.abs().sum()) == 0.0
+        have = [gathered[r][i] for r in range(world) if gathered[r][i] is not None]
+        if not have:                                   # unused on all ranks: grad stays None (DDP find_unused semantics)
+            ok = ok and p.grad is None
         else:
-            want = sum(torch.tensor(gathered[r][i]) for r in range(world)) / world
-            ok = ok and torch.allclose(p.grad, want, atol=1e-6)
+            want = sum(torch.tensor(g) for g in have) / world
+            ok = ok and p.grad is not None and torch.allclose(p.grad, want, atol=1e-6)
+    ok = ok and net[2].weight.grad is None and net[1].weight.grad is not None
+    # an optimiser step must not create state for the never-trained weights
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    opt.step()
+    ok = ok and net[2].weight not in opt.state and net[0].weight in opt.state
+    # (2) overlapped form: hooks issue the buckets during backward; same numbers as (1), twice in a row
+    net2 = make()
+    red = pd.GradientReducer(net2.parameters(), bucket_bytes=256)
+    for _ in range(2):
+        for p in net2.parameters():
+            p.grad = None
+        h = net2[0](x)
+        (net2[1](h).sum() if rank == 0 else h.sum()).backward()
+        nb2 = red.finish()
+        for pa, pb in zip(net.parameters(), net2.parameters()):
+            ok = ok and ((pa.grad is None) == (pb.grad is None)) and (pa.grad is None or torch.allclose(pa.grad, pb.grad, atol=1e-6))
+    ok = ok and nb2 == nb
+    # (3) bf16 on the wire
+    net3 = make()
+    h = net3[0](x)
+    (net3[1](h).sum() if rank == 0 else h.sum()).backward()
+    pd.allreduce_gradients(net3.parameters(), bucket_bytes=256, comm_dtype=torch.bfloat16)
+    for pa, pb in zip(net.parameters(), net3.parameters()):
+        ok = ok and (pa.grad is None or torch.allclose(pa.grad, pb.grad, rtol=2e-2, atol=1e-2))
+    # (4) BatchNorm statistics: every rank ends with rank 0's buffers
+    with torch.no_grad():
+        net[3].running_mean.fill_(float(rank + 1))
+        net[3].num_batches_tracked.fill_(rank + 5)
+    n_buf = pd.sync_buffers(net)
+    ok = ok and n_buf == 3 and float(net[3].running_mean[0]) == 1.0 and int(net[3].num_batches_tracked) == 5
     t = pd.max_over_ranks(1.0 + rank)
     out[rank] = (ok, t, pd.shard_scenes(5, rank, world))
     dist.destroy_process_group()

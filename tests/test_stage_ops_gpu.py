@@ -109,7 +109,9 @@ def test_mlp_rows_matches_modules(dtype, tol, n_out, sigmoid, hidden):
     head = head.to(DEV)
     got = stage_ops.mlp_rows(head, x.to(DEV).to(dtype), idx_a.to(DEV), idx_b.to(DEV))
     assert got.shape == (4000, n_out) and got.dtype == dtype
-    assert (got.float().cpu() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    err = (got.float().cpu() - want).abs().max().item()
+    # fp32: absolute; bf16: bound relative to the output range (not the parity configuration)
+    assert err <= (tol if dtype == torch.float32 else tol * max(1.0, want.abs().max().item())), err
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
