@@ -138,8 +138,10 @@ int pbn_up_table(const int32_t* parent_row, const int32_t* child_k, const int32_
  * Sparse convolution forward (implicit GEMM on MFMA), replacing MinkowskiConvolution / MinkowskiConvolutionTranspose /
  * MinkowskiLinear forward as used at network/Mink.py:293-350 and network/PBNet.py:43-82,121-123,249,273-277:
  *     out[o, c] = act( (sum_k sum_ci in[nbr[o,k], ci] * W[k, ci, c]) * scale[c] + shift[c] + residual[o, c] )
- *  in_feat   [*, ld_in]  T   input slab (pointer already advanced to the first input column); padding columns
- *                            up to vecs_per_offset*(16/sizeof(T)) must be readable and finite
+ *  in_feat   [n_in, ld_in] T  input slab (pointer already advanced to the first input column); padding columns
+ *                            up to vecs_per_offset*(16/sizeof(T)) must be readable and finite.  Rows are gathered
+ *                            with 32-bit byte offsets: n_in*ld_in*sizeof(T) must be < 2 GiB, else PBN_ERR_RANGE
+ *                            (entries of nbr outside [0, n_in) read zeros, never memory outside the slab)
  *  nbr       [n_out, n_offsets] i32 or NULL (identity: 1x1 convolution / linear, n_offsets must be 1)
  *  row_perm  optional processing order (tile position p computes output row row_perm[p])
  *  w_packed  weights in MFMA fragment order: [n_steps][cout_padded/16][64 lanes][16 bytes] where lane l of
@@ -154,7 +156,7 @@ int pbn_up_table(const int32_t* parent_row, const int32_t* child_k, const int32_
  *                combined in a fixed order by a second kernel; NULL / too small => single-pass launch.
  *  fp32 accumulation, fixed summation order: results are deterministic (bit-identical run to run).
  */
-int pbn_spconv_forward(const void* in_feat, int ld_in, const int32_t* nbr, int n_offsets, const int32_t* row_perm,
+int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets, const int32_t* row_perm,
                        const int32_t* n_out_dev, int n_out, const void* w_packed, int vecs_per_offset, int n_steps,
                        int cout_padded, const float* scale, const float* shift, const void* residual, int ld_res,
                        int relu, void* out_feat, int ld_out, int dtype, int rows_per_wave, void* workspace,

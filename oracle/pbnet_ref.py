@@ -166,6 +166,10 @@ def cluster_stage(sd, cfg, s1, xyz_original, ins_label, task, training=False):
         out["mask_scores"] = (mask_score, torch.cat(list_gt_mask, dim=0))
     out["proposals"] = get_proposal(list_ins_idx, mask_score)
     out["local_scene_rows"] = sem_feat_tensor.shape[0]
+    # row-level view for the tests: (local scene, point index, mask score before the threshold) of every row
+    out["row_scene"] = torch.cat([torch.full((len(x),), i, dtype=torch.int64) for i, x in enumerate(list_ins_idx)])
+    out["row_point"] = torch.cat(list_ins_idx).long()
+    out["row_mask_score"] = mask_score.view(-1)
     # ---- score branch (PBNet.py:255-279)
     proposals_idx, proposals_offset, _, _ = out["proposals"]
     if proposals_offset.shape[0] == 1:

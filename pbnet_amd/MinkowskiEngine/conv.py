@@ -119,7 +119,7 @@ def spconv_forward(feats, nbr, n_out, packed, scale=None, shift=None, residual=N
         assert residual.stride(1) == 1 and residual.dtype == dtype and residual.shape[1] >= cout_p
     ws = _workspace(feats.device)
     rc = N.lib().pbn_spconv_forward(
-        N.c_vp(feats.data_ptr()), feats.stride(0), None if nbr is None else N.c_vp(nbr.data_ptr()), k,
+        N.c_vp(feats.data_ptr()), feats.stride(0), int(feats.shape[0]), None if nbr is None else N.c_vp(nbr.data_ptr()), k,
         None if row_perm is None else N.c_vp(row_perm.data_ptr()), None, int(n_out), N.c_vp(w.data_ptr()), vpo, n_steps,
         cout_p, None if scale is None else N.c_vp(scale.data_ptr()), None if shift is None else N.c_vp(shift.data_ptr()),
         None if residual is None else N.c_vp(residual.data_ptr()), 0 if residual is None else residual.stride(0),

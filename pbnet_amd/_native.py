@@ -70,7 +70,7 @@ SIGNATURES = {
                                   c_i32p, c_vp, c_size, c_vp]),
     "pbn_kernel_map": (c_int, [c_i32p, c_i32p, c_int, c_i32p, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_up_table": (c_int, [c_i32p, c_i32p, c_i32p, c_int, c_i32p, c_vp]),
-    "pbn_spconv_forward": (c_int, [c_vp, c_int, c_i32p, c_int, c_i32p, c_i32p, c_int, c_vp, c_int, c_int, c_int,
+    "pbn_spconv_forward": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_i32p, c_int, c_vp, c_int, c_int, c_int,
                                    c_f32p, c_f32p, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "pbn_gather_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "pbn_segment_pool_workspace_bytes": (c_size, [c_int, c_int]),
@@ -121,6 +121,7 @@ SIGNATURES = {
                                        c_int, c_vp, c_size, c_vp, ctypes.POINTER(ctypes.c_float)]),
 }
 
+PBN_OK, PBN_ERR_ARG, PBN_ERR_WORKSPACE, PBN_ERR_HIP, PBN_ERR_RANGE, PBN_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 ERRORS = {-1: "PBN_ERR_ARG", -2: "PBN_ERR_WORKSPACE", -3: "PBN_ERR_HIP", -4: "PBN_ERR_RANGE", -5: "PBN_ERR_UNSUPPORTED"}
 
 

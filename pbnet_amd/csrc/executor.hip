@@ -209,7 +209,7 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
         void* out = base(o.out_buf) + (size_t)o.out_col * es;
         const void* res = o.res_buf >= 0 ? base(o.res_buf) + (size_t)o.res_col * es : nullptr;
         if (events) PBN_HIP_CHECK(hipEventRecord(events[2 * i], (hipStream_t)stream));
-        const int rc = pbn_spconv_forward(in, ld(o.in_buf), nbr, K, nullptr, nullptr, n_rows[o.level_out], o.w, o.vpo,
+        const int rc = pbn_spconv_forward(in, ld(o.in_buf), n_rows[o.level_in], nbr, K, nullptr, nullptr, n_rows[o.level_out], o.w, o.vpo,
                                           o.n_steps, o.cout_p, o.scale, o.shift, res, o.res_buf >= 0 ? ld(o.res_buf) : 0,
                                           o.relu, out, ld(o.out_buf), dtype, 0, splitk_ws, splitk_bytes, stream);
         if (rc != PBN_OK) return rc;

@@ -50,6 +50,7 @@ struct ConvArgs {
     const void* residual;
     void* out;
     int ld_in, ld_res, ld_out;
+    unsigned in_bytes, w_bytes;   // extents of the two buffer resources (< 2 GiB, checked by pbn_spconv_forward)
     int K, vpo, n_steps, ntiles_total;
     int n_out, relu;
     int ksplit;          // >1: this launch writes fp32 partial sums, k_spconv_reduce applies the epilogue
@@ -266,10 +267,12 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
 
     // Both operands come in through buffer resources: a gather is ONE instruction with a 32-bit per-lane byte offset,
     // and a fragment without a neighbour simply uses an out-of-range offset -- the hardware bounds check returns
-    // zeros, so the inner loop has no exec-mask branches and no 64-bit address arithmetic.  (Slabs must stay < 2 GiB.)
+    // zeros, so the inner loop has no exec-mask branches and no 64-bit address arithmetic.  num_records is the exact
+    // extent of the slab / the packed weights (both < 2 GiB: pbn_spconv_forward returns PBN_ERR_RANGE otherwise), so a
+    // corrupt rulebook entry cannot read outside them either.
     const unsigned long long in_addr = (unsigned long long)a.in, w_addr = (unsigned long long)a.w;
-    const i32x4 rs_in = {(int)(unsigned)in_addr, (int)(unsigned)(in_addr >> 32), (int)0x80000000u, 0x00020000};
-    const i32x4 rs_w = {(int)(unsigned)w_addr, (int)(unsigned)(w_addr >> 32), (int)0x80000000u, 0x00020000};
+    const i32x4 rs_in = {(int)(unsigned)in_addr, (int)(unsigned)(in_addr >> 32), (int)a.in_bytes, 0x00020000};
+    const i32x4 rs_w = {(int)(unsigned)w_addr, (int)(unsigned)(w_addr >> 32), (int)a.w_bytes, 0x00020000};
     constexpr unsigned OOB = 0x80000000u;  // >= num_records: the bounds check turns the load into zeros
     const unsigned ld_bytes = (unsigned)a.ld_in * (unsigned)sizeof(T);
     const int vshift = (vpo == 2) ? 1 : 0;
@@ -580,14 +583,14 @@ __global__ __launch_bounds__(256) void k_gather_rows(const uint4* __restrict__ i
 
 using namespace pbn;
 
-extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, const int32_t* nbr, int n_offsets,
+extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
                                   const int32_t* row_perm, const int32_t* n_out_dev, int n_out, const void* w_packed,
                                   int vecs_per_offset, int n_steps, int cout_padded, const float* scale,
                                   const float* shift, const void* residual, int ld_res, int relu, void* out_feat,
                                   int ld_out, int dtype, int rows_per_wave, void* workspace, size_t workspace_bytes,
                                   pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (n_out < 0 || n_offsets < 1 || vecs_per_offset < 1 || n_steps < 1 || cout_padded < 16 || (cout_padded & 15))
+    if (n_out < 0 || n_in < 0 || n_offsets < 1 || vecs_per_offset < 1 || n_steps < 1 || cout_padded < 16 || (cout_padded & 15))
         return PBN_ERR_ARG;
     if (!(vecs_per_offset == 1 || vecs_per_offset == 2 || (vecs_per_offset & 3) == 0)) return PBN_ERR_ARG;
     if (n_steps != (n_offsets * vecs_per_offset + 3) / 4) return PBN_ERR_ARG;
@@ -597,7 +600,14 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, const int32_t*
     const int esz = dtype == PBN_F32 ? 4 : 2;
     if ((ld_in * esz) % 16 || (ld_out * esz) % 8 || (residual && (ld_res * esz) % 8)) return PBN_ERR_ARG;
     if (((uintptr_t)in_feat | (uintptr_t)w_packed) & 15) return PBN_ERR_ARG;
+    // gathers address the slab with 32-bit byte offsets through a buffer resource (k_spconv): a slab or weight block of
+    // 2 GiB or more cannot be addressed -- refuse it instead of silently gathering zeros past the limit
+    const unsigned long long in_extent = (unsigned long long)n_in * (unsigned long long)ld_in * (unsigned long long)esz;
+    const unsigned long long w_extent = (unsigned long long)n_steps * (unsigned long long)(cout_padded / 16) * 1024ull;
+    if (in_extent >= 0x80000000ull || w_extent >= 0x80000000ull) return PBN_ERR_RANGE;
+    if (!nbr && n_in < n_out) return PBN_ERR_ARG;   // identity map reads row o of the input
     ConvArgs a;
+    a.in_bytes = (unsigned)in_extent; a.w_bytes = (unsigned)w_extent;
     a.in = in_feat; a.nbr = nbr; a.row_perm = row_perm; a.n_out_dev = n_out_dev; a.w = w_packed; a.scale = scale;
     a.shift = shift; a.residual = residual; a.out = out_feat; a.ld_in = ld_in; a.ld_res = ld_res; a.ld_out = ld_out;
     a.K = n_offsets; a.vpo = vecs_per_offset; a.n_steps = n_steps; a.ntiles_total = cout_padded / 16; a.n_out = n_out;

@@ -55,3 +55,23 @@ def test_cpu_tensors_are_refused():
     z = torch.zeros(4, 3)
     with pytest.raises(RuntimeError):
         pbnet_ops.cluster_device(z, z, torch.zeros(4, dtype=torch.int32), torch.tensor([4], dtype=torch.int32), 0.04, 31)
+
+
+def test_spconv_refuses_slabs_it_cannot_address():
+    """k_spconv gathers with 32-bit byte offsets through a buffer resource: an input slab (or packed weight block) of
+    2 GiB or more must come back as PBN_ERR_RANGE -- the argument checks run on the host before any launch, so this
+    needs no GPU (the pointers below are never dereferenced)."""
+    from pbnet_amd import _native as N
+    lib = N.lib()
+    vp = N.c_vp
+    fake = 1 << 20                                    # 16-byte aligned, never touched
+
+    def call(n_in, ld, dtype, n_out=128, n_steps=27 * 3, cout_p=96):
+        return lib.pbn_spconv_forward(vp(fake), ld, n_in, vp(fake), 27, None, None, n_out, vp(fake), 12, n_steps, cout_p, None,
+                                      None, None, 0, 0, vp(fake), cout_p, dtype, 0, None, 0, None)
+    # 1.2 M voxels x 3 TTA copies x 384 ch fp32 = 5.5 GB: refused; the bf16 / 96-channel slabs of the same scene pass the
+    # check only when they fit
+    assert call(3 * 1200000, 384, 0) == N.PBN_ERR_RANGE
+    assert call(-(-(1 << 31) // (96 * 2)), 96, 1) == N.PBN_ERR_RANGE      # the first row count that reaches 2 GiB
+    assert call(-1, 96, 1) == N.PBN_ERR_ARG
+    assert call(100, 96, 1, n_out=0) == N.PBN_OK                          # in range, nothing to do

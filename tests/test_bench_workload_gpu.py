@@ -1,0 +1,140 @@
+"""GPU tier: the BENCHMARKED configuration itself (BASELINE configs[1]: bench.py's default workload, seed 2, 161 517
+points / 146 038 voxels at 2 cm, bench.py's model) -- full PBNet.forward against oracle/pbnet_ref.py in fp32, and the
+bf16 configuration of the bench line against the fp32 one with a stated contract for the integer outputs.
+
+Contract (written here, asserted below):
+  fp32  stage 1 (backbone + heads): |diff| <= 1e-4 ABSOLUTE on every feature / score / offset.
+        stage 2: sem_pred, grouping and the local scenes are integer functions of teacher-forced inputs -> identical.
+        A row's proposal membership is `mask_score > 0.45`; the device's mask score may differ from the oracle's by
+        up to 1e-4, so membership must be identical EXCEPT on rows whose oracle score lies within 1e-4 of the threshold
+        (the test counts them; zero on this scene).  With identical membership: proposals_idx / proposals_offset /
+        surviving scene ids bit-equal, proposals_ms and clt_scores <= 1e-4.
+  bf16  (feature slabs bf16, fp32 accumulation): sem_pred identical (teacher-forced), the same local scenes, the same
+        NUMBER of proposals; membership differs from fp32 only where bf16 rounding moves a mask score across 0.45:
+        symmetric difference <= BF16_MEMBERSHIP_BOUND of the fp32 membership, every differing row has an fp32 mask
+        score within BF16_SCORE_BAND of the threshold; clt_scores within BF16_SCORE_TOL.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pbnet_ref
+from pbnet_amd import synth
+from pbnet_amd.config import get_config
+from pbnet_amd.network.PBNet import PBNet, MASK_THD
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+BF16_MEMBERSHIP_BOUND = 0.02      # fraction of the fp32 proposal rows (measured on MI355X: see the printed figure)
+BF16_SCORE_BAND = 0.05            # |fp32 mask score - 0.45| of every row whose membership differs
+BF16_SCORE_TOL = 0.05
+
+
+@pytest.fixture(scope="module")
+def case():
+    cfg = get_config(test=True)
+    torch.manual_seed(22)                         # bench.py:build_workload
+    model = PBNet(cfg)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    batch, teacher, info = synth.make_val_batch(seed=2, copies=1)      # bench.py WORKLOADS["c2"] defaults
+    assert info["n_points"] == 161517 and info["n_voxels"] == 146038
+    t = torch.from_numpy
+    b = {k: t(v) for k, v in batch.items()}
+    tt = {k: t(v) for k, v in teacher.items()}
+    # the oracle, once (~8 s of host time)
+    s1 = pbnet_ref.backbone_stage(sd, b["feat_voxel"], b["xyz_voxel"], b["v2p_index"])
+    s1t = dict(s1)
+    s1t["sem_pred_score_p"] = tt["sem_score"]
+    s1t["sem_pred_score_sfp"] = torch.softmax(tt["sem_score"], 1)
+    s1t["offset_pred_p"] = tt["offset"]
+    s1t["sem_pred_p"] = tt["sem_score"].max(1)[1]
+    want = pbnet_ref.cluster_stage(sd, cfg, s1t, b["xyz_original"], None, "test")
+    return cfg, model, b, tt, s1, want
+
+
+def _forward(model, b, tt, dtype):
+    bd = {k: v.to(DEV) for k, v in b.items()}
+    bd["feat_voxel"] = bd["feat_voxel"].to(dtype)
+    td = {k: v.to(DEV) for k, v in tt.items()}
+    with torch.no_grad():
+        return model(bd["feat_voxel"], bd["xyz_voxel"], bd["xyz_original"], bd["v2p_index"], None, 1, "test", teacher=td)
+
+
+def _membership(idx, scene_ids):
+    """set of (local scene id, point index) from proposals_idx [S,2] with dense ids + the surviving scene ids."""
+    idx = idx.cpu().numpy()
+    sid = scene_ids.cpu().numpy()[idx[:, 0]]
+    return set(zip(sid.tolist(), idx[:, 1].tolist()))
+
+
+def test_bench_scene_stage1_fp32(case):
+    cfg, model, b, tt, s1, want = case
+    with torch.no_grad():
+        got = model.backbone_stage(b["feat_voxel"].to(DEV), b["xyz_voxel"].to(DEV), b["v2p_index"].to(DEV))
+    for k in ("point_feat_p", "sem_pred_score_p", "sem_pred_score_sfp", "offset_pred_p"):
+        err = (got[k].cpu() - s1[k]).abs().max().item()
+        print("%s: max |diff| %.3e over %s" % (k, err, tuple(s1[k].shape)))
+        assert err <= TOL, (k, err)
+
+
+def test_bench_scene_forward_fp32_vs_oracle(case):
+    cfg, model, b, tt, s1, want = case
+    ret = _forward(model, b, tt, torch.float32)
+    assert torch.equal(ret["sem_pred_p"].cpu(), tt["sem_score"].max(1)[1])
+    wi, wo, wv, wm = want["proposals"]
+    gi, go, gv, gm = ret["proposals"]
+    n_scenes = want["n_local_scenes"]
+    print("oracle: %d local scenes, %d rows, %d proposals, %d proposal rows" % (n_scenes, want["local_scene_rows"], len(wo) - 1, len(wi)))
+    assert len(wo) - 1 >= 10
+    m_got, m_want = _membership(gi, gv), _membership(wi, wv)
+    diff = m_got ^ m_want
+    score_of = {}
+    if diff:                                                   # only rows within 1e-4 of the threshold may differ
+        rs, rp, sc = want["row_scene"].numpy(), want["row_point"].numpy(), want["row_mask_score"].numpy()
+        for s_, p_, v_ in zip(rs.tolist(), rp.tolist(), sc.tolist()):
+            score_of[(s_, p_)] = v_
+        for key in diff:
+            assert abs(score_of[key] - MASK_THD) <= TOL, (key, score_of[key])
+    near = int(((want["row_mask_score"] - MASK_THD).abs() <= TOL).sum())
+    print("membership: %d rows differ (rows within 1e-4 of the threshold: %d of %d)" % (len(diff), near, want["local_scene_rows"]))
+    if not diff:
+        assert torch.equal(go.cpu(), wo), "proposals_offset"
+        assert torch.equal(gi.cpu(), wi), "proposals_idx"
+        assert torch.equal(gv.cpu(), wv.long()), "surviving local scene ids"
+        e_ms = (gm.cpu() - wm).abs().max().item()
+        e_sc = (ret["clt_scores"].cpu() - want["clt_scores"]).abs().max().item()
+        print("proposals_ms max |diff| %.3e, clt_scores max |diff| %.3e" % (e_ms, e_sc))
+        assert e_ms <= TOL and e_sc <= TOL
+    else:                                                      # same proposals, scores compared where defined
+        assert go.shape == wo.shape and torch.equal(gv.cpu(), wv.long())
+        assert (ret["clt_scores"].cpu() - want["clt_scores"]).abs().max().item() <= 10 * TOL
+
+
+def test_bench_scene_bf16_vs_fp32_contract(case):
+    cfg, model, b, tt, s1, want = case
+    r32 = _forward(model, b, tt, torch.float32)
+    r16 = _forward(model, b, tt, torch.bfloat16)
+    r16b = _forward(model, b, tt, torch.bfloat16)
+    for k in (0, 1, 2):                                        # run to run bit-identical
+        assert torch.equal(r16["proposals"][k], r16b["proposals"][k])
+    assert torch.equal(r16["clt_scores"], r16b["clt_scores"])
+    assert torch.equal(r16["sem_pred_p"], r32["sem_pred_p"])
+    i32, o32, v32, _ = r32["proposals"]
+    i16, o16, v16, _ = r16["proposals"]
+    assert torch.equal(v16, v32), "the same local scenes survive"
+    assert o16.shape == o32.shape
+    m32, m16 = _membership(i32, v32), _membership(i16, v16)
+    diff = m32 ^ m16
+    frac = len(diff) / max(len(m32), 1)
+    rs, rp, sc = want["row_scene"].numpy(), want["row_point"].numpy(), want["row_mask_score"].numpy()
+    score_of = dict(zip(zip(rs.tolist(), rp.tolist()), sc.tolist()))
+    band = max((abs(score_of[k] - MASK_THD) for k in diff), default=0.0)
+    e_sc = (r16["clt_scores"].float() - r32["clt_scores"].float()).abs().max().item()
+    e_feat = (r16["sem_pred_score_p"].float() - r32["sem_pred_score_p"].float()).abs().max().item()
+    print("bf16 vs fp32: %d of %d proposal rows differ (%.4f %%), widest |score - 0.45| among them %.4f, "
+          "clt_scores max |diff| %.4f, teacher-forced scores |diff| %.1e" % (len(diff), len(m32), 100 * frac, band, e_sc, e_feat))
+    assert frac <= BF16_MEMBERSHIP_BOUND
+    assert band <= BF16_SCORE_BAND
+    assert e_sc <= BF16_SCORE_TOL

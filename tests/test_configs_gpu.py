@@ -1,0 +1,203 @@
+"""GPU tier: the two BASELINE.json configurations that had no -m gpu test at their own size.
+
+configs[3]  1.2 M points / 1 cm voxels (bench.py --workload c4: 1 106 686 points, 1 020 822 voxels): the sizes at which
+            16-bit coordinate packing, hash-table load and 32-bit buffer offsets bite.  Checked here:
+            * coordinate pyramid (all five levels) == the oracle's, as sets and in first-occurrence order;
+            * k=3 kernel map of EVERY row and k=5 map of sampled rows == a sorted-key dictionary lookup;
+            * one fp32 and one bf16 convolution on the whole slab, spot rows against the oracle's arithmetic;
+            * grouping of the largest class segment == oracle/pb_cluster_ref.c bit for bit;
+            * the full forward in bf16 returns well-formed proposals, run-to-run identical.
+configs[2]  bf16 training step on a ScanNet-sized scene (one rank's share of batch 8): loss and sampled gradients
+            against the fp32 step of the same model on the same scene."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pb_cluster_ref as cluster_oracle
+from oracle import sparse_ref as R
+import pbnet_amd.MinkowskiEngine as ME
+from pbnet_amd import pbnet_ops, synth
+from pbnet_amd.config import get_config
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+C4 = dict(seed=3, room=(6.4, 5.2, 2.7), n_boxes=14, pitch=0.0112, voxel=0.01)     # bench.py WORKLOADS["c4"]
+
+
+@pytest.fixture(scope="module")
+def c4():
+    batch, teacher, info = synth.make_val_batch(copies=1, **C4)
+    assert info["n_voxels"] > 1000000 and info["n_points"] > 1100000
+    return batch, teacher, info
+
+
+def test_c4_coordinate_pyramid_and_kernel_maps(c4):
+    batch, _, info = c4
+    coords = batch["xyz_voxel"]
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(DEV))
+    ref = R.CoordinateManager(coords)
+    for s in (1, 2, 4, 8, 16):
+        want = ref.get_coords(s)
+        got = cm.coordinates(s).cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), "stride %d" % s
+    print("levels:", [cm.num_rows(s) for s in (1, 2, 4, 8, 16)])
+    # k=3 at stride 1 and 4: every row, every offset, against a sorted-key lookup
+    for s in (1, 4):
+        nbr = cm.kernel_map(s, 3).cpu().numpy()
+        c = ref.get_coords(s).astype(np.int64)
+        index = R.KeyIndex(c)
+        offs = R.kernel_offsets(3, s)
+        pairs = 0
+        for k in range(27):
+            q = c.copy()
+            q[:, 1:] += offs[k][None, :]
+            want = index.lookup(q)
+            assert np.array_equal(nbr[:, k], want), "k=3 stride %d offset %d" % (s, k)
+            pairs += int((want >= 0).sum())
+        print("k=3 stride %d: %d pairs, all %d x 27 entries equal" % (s, pairs, len(c)))
+    # k=5 (the stem): 20 000 sampled rows
+    nbr5 = cm.kernel_map(1, 5)
+    rng = np.random.default_rng(0)
+    rows = np.sort(rng.choice(len(coords), 20000, replace=False))
+    got5 = nbr5[torch.from_numpy(rows).to(DEV)].cpu().numpy()
+    c = coords.astype(np.int64)
+    index = R.KeyIndex(c)
+    offs = R.kernel_offsets(5, 1)
+    for k in range(125):
+        q = c[rows].copy()
+        q[:, 1:] += offs[k][None, :]
+        assert np.array_equal(got5[:, k], index.lookup(q)), "k=5 offset %d" % k
+
+
+@pytest.mark.parametrize("dtype,cin,cout,tol", [(torch.float32, 32, 32, 1e-4), (torch.bfloat16, 96, 96, 3e-2)])
+def test_c4_convolution_spot_rows(c4, dtype, cin, cout, tol):
+    batch, _, _ = c4
+    coords = batch["xyz_voxel"]
+    n = len(coords)
+    torch.manual_seed(11)
+    feats = torch.randn(n, cin)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=3, dimension=3)
+    w = conv.kernel.detach().clone()
+    x = ME.SparseTensor(feats.to(dtype), torch.from_numpy(coords), device=DEV)
+    with torch.no_grad():
+        got = conv.to(DEV)(x).F
+    # spot rows: the first / last tiles and 4096 random rows, oracle arithmetic on the gathered neighbours
+    rng = np.random.default_rng(1)
+    rows = np.unique(np.concatenate([np.arange(256), np.arange(n - 256, n), rng.choice(n, 4096, replace=False)]))
+    c = coords.astype(np.int64)
+    index = R.KeyIndex(c)
+    offs = R.kernel_offsets(3, 1)
+    fq = feats.to(dtype).float()                        # what the slab holds
+    wq = w.to(dtype).float()
+    want = torch.zeros(len(rows), cout)
+    for k in range(27):
+        q = c[rows].copy()
+        q[:, 1:] += offs[k][None, :]
+        src = index.lookup(q)
+        hit = src >= 0
+        if hit.any():
+            want[torch.from_numpy(np.nonzero(hit)[0])] += fq[torch.from_numpy(src[hit])] @ wq[k]
+    g = got[torch.from_numpy(rows).to(DEV)].float().cpu()[:, :cout]
+    err = (g - want).abs().max().item()
+    print("%s %d->%d on %d rows: spot max |diff| %.3e (|want| max %.2f)" % (dtype, cin, cout, n, err, want.abs().max().item()))
+    assert err <= tol
+
+
+def test_c4_grouping_largest_class_segment(c4):
+    batch, teacher, _ = c4
+    sem = teacher["sem_score"].argmax(1)
+    counts = np.bincount(sem, minlength=20)
+    counts[:2] = 0
+    cls = int(counts.argmax())
+    sel = np.nonzero(sem == cls)[0]
+    org = batch["xyz_original"][sel]
+    off = (org + teacher["offset"][sel]).astype(np.float32)
+    s = np.full(len(sel), cls, np.int32)
+    seg = np.array([len(sel), 0, 0], np.int32)
+    cfg = get_config(test=True)
+    res = pbnet_ops.cluster_device(torch.from_numpy(off).to(DEV), torch.from_numpy(org).to(DEV), torch.from_numpy(s).to(DEV),
+                                   torch.from_numpy(seg).to(DEV), cfg.radius, cfg.min_pts)
+    ref = cluster_oracle.binary_cluster(off, org, s, seg, float(cfg.radius), int(cfg.min_pts))
+    nc = int(res.n_clusters.item())
+    print("class %d: %d points, %d clusters" % (cls, len(sel), nc))
+    assert nc == ref["center"].shape[0] and nc >= 1
+    assert np.array_equal(res.cluster_id.cpu().numpy(), ref["cluster_id"])
+    assert np.array_equal(res.den.cpu().numpy(), ref["den_queue"])
+    assert np.array_equal(res.centers[:3 * nc].cpu().numpy().view(np.int32), ref["center"].reshape(-1).view(np.int32))
+
+
+def test_c4_full_forward_bf16_well_formed(c4):
+    from pbnet_amd.network.PBNet import PBNet
+    batch, teacher, info = c4
+    cfg = get_config(test=True)
+    torch.manual_seed(22)
+    model = PBNet(cfg).to(DEV).eval()
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in batch.items()}
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in teacher.items()}
+    outs = []
+    for _ in range(2):
+        with torch.no_grad():
+            r = model(b["feat_voxel"].to(torch.bfloat16), b["xyz_voxel"], b["xyz_original"], b["v2p_index"], None, 1, "test", teacher=t)
+        torch.cuda.synchronize()
+        outs.append(r)
+    idx, off, ids, ms = outs[0]["proposals"]
+    n = info["n_points"]
+    assert off.shape[0] - 1 >= 10 and off[-1].item() == idx.shape[0] == ms.shape[0]
+    assert 0 <= int(idx[:, 1].min()) and int(idx[:, 1].max()) < n
+    assert (off[1:] > off[:-1]).all() and torch.isfinite(outs[0]["clt_scores"].float()).all()
+    assert outs[0]["clt_scores"].shape[0] == off.shape[0] - 1
+    for k in (0, 1, 2, 3):
+        assert torch.equal(outs[0]["proposals"][k], outs[1]["proposals"][k])
+    assert torch.equal(outs[0]["clt_scores"], outs[1]["clt_scores"])
+    print("c4 forward: %d proposals over %d rows" % (off.shape[0] - 1, idx.shape[0]))
+
+
+# ---- configs[2] ---------------------------------------------------------------------------------------------------
+
+def _train_once(dtype, batch_np, teacher_np, cfg):
+    from pbnet_amd.network.PBNet import PBNet, model_fn
+    torch.manual_seed(22)
+    model = PBNet(cfg).to(DEV).train()
+    t = torch.from_numpy
+    batch = {k: t(v).to(DEV) for k, v in batch_np.items()}
+    batch["feat_voxel"] = batch["feat_voxel"].to(dtype)
+    teacher = {k: t(v).to(DEV) for k, v in teacher_np.items()}
+    fwd = model.forward
+    model.forward = lambda *a, **kw: fwd(*a, teacher=teacher, **kw)
+    loss, pred, visual, meter = model_fn(batch, model, 1, cfg, "train")
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {n_: p.grad.detach().float().cpu() for n_, p in model.named_parameters() if p.grad is not None}
+    return float(loss), visual, grads, int(pred["proposals"][1].shape[0]) - 1
+
+
+def test_c3_bf16_training_step_at_scene_size_vs_fp32():
+    """BASELINE configs[2], one rank's share: a 150 k-voxel scene, bf16 feature slabs / fp32 master weights and
+    accumulation, model_fn forward + losses + backward.  Contract: every loss term within 2 % (absolute 2e-2) of the
+    fp32 step, the same number of proposals, and sampled gradients aligned with the fp32 gradients (cosine >= 0.98,
+    norm ratio within 10 %): bf16 changes rounding, not the step."""
+    batch_np, teacher_np, info = synth.make_train_batch(seed=10, copies=1)
+    assert info["n_voxels"] > 140000
+    cfg = get_config(batch_size=1, cluster_epoch=0)
+    l32, v32, g32, p32 = _train_once(torch.float32, batch_np, teacher_np, cfg)
+    l16, v16, g16, p16 = _train_once(torch.bfloat16, batch_np, teacher_np, cfg)
+    print("loss fp32 %.5f bf16 %.5f; proposals %d / %d" % (l32, l16, p32, p16))
+    for k in v32:
+        print("  %-18s fp32 %.5f  bf16 %.5f" % (k, v32[k], v16[k]))
+        assert abs(v32[k] - v16[k]) <= 2e-2 * max(1.0, abs(v32[k])), k
+    assert p32 == p16 and p32 >= 5
+    assert set(g32) == set(g16)
+    names = ["MEUnet.conv0p1s1.kernel", "MEUnet.block1.0.conv1.kernel", "MEUnet.block4.2.conv2.kernel",
+             "MEUnet.convtr7p2s2.kernel", "MEUnet.block8.1.conv2.kernel", "MEUnet.final_sematic.kernel",
+             "D_Unet.block2.0.conv1.kernel", "D_Unet.block8.0.downsample.0.kernel", "score_Unet.block3.1.conv1.kernel",
+             "score_Unet.conv4p8s2.kernel", "linear_binary.3.linear.weight", "linear_IOU.0.linear.weight",
+             "MEUnet.bn0.bn.weight", "score_Unet.block6.0.norm2.bn.bias"]
+    worst = 1.0
+    for n_ in names:
+        a, b = g16[n_].reshape(-1).double(), g32[n_].reshape(-1).double()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        ratio = float(a.norm() / (b.norm() + 1e-30))
+        print("  %-40s cos %.5f  |g16|/|g32| %.4f" % (n_, cos, ratio))
+        worst = min(worst, cos)
+        assert cos >= 0.98 and 0.9 <= ratio <= 1.1, (n_, cos, ratio)
+    print("worst cosine %.5f" % worst)
