@@ -8,9 +8,13 @@ workload: configs[1] -- one synthetic ScanNet-sized scene (seed 2: 161 517 point
           the reference's init rule).  Randomly initialised heads cannot produce instances, so the semantic / offset
           head outputs are overwritten by teacher-forced values AFTER they have been computed; every
           stage of the path therefore runs inside the timed region on realistic, data-dependent sizes.
-step    : one PBNet.forward over one scene per rank.  N > 1: every rank owns its own copy of the scene (identical
-          per-GPU work), no data-path collective (scenes are independent at inference) -> weak scaling; the process
-          group only carries the barrier and the max-over-ranks of the elapsed time.
+step    : one PBNet.forward over one scene per rank (1 rotated copy).  N > 1: every rank owns its own copy of the scene
+          (identical per-GPU work), no data-path collective (scenes are independent at inference) -> weak scaling; the
+          process group (RCCL) only carries the barrier and the max-over-ranks of the elapsed time.  The process group is
+          initialised at N = 1 too (one all-reduce + barrier) so that the RCCL path is known to work on the box.
+timing  : W warm-up steps, then `--repeats` timed blocks of EXACTLY K steps, each bracketed by barrier +
+          torch.cuda.synchronize() on both sides and reduced with MAX over ranks.  `value` / `ms_per_step` come from the
+          MEDIAN block; p10 / p90 over the blocks are reported beside it.
 in flight: the K steps of a rank are taken round-robin by `--inflight` host threads (default 4), each on its own HIP
           stream: most launches of the path are far too small for 256 CUs, so kernels of independent scenes overlap
           on the device and one scene's host read-backs hide behind another's kernels.  Results are bit-identical to
@@ -18,16 +22,20 @@ in flight: the K steps of a rank are taken round-robin by `--inflight` host thre
           inverse rate); the latency of a scene alone on the GPU is config.one_scene_in_flight_ms_per_scene, and
           `--inflight 1` runs the reference's one-scene-at-a-time loop.
 
-Also on the JSON line:
-  roofline     -- the dominant kernel family (k_spconv, csrc/spconv.hip): algorithmic bytes of every launch (SURVEY.md
-                  8d: (V_in*C_in + V_out*C_out)*b + K*C_in*C_out*b + 8*P) divided by that launch's duration, measured
-                  with HIP events on the launching stream in an instrumented pass over the same steps in the same
-                  in-flight mode (a launch that shares the CUs with other streams' kernels takes longer: the per-launch
-                  figure falls while the whole-job rate rises; `one_scene_in_flight` holds the same figures for
-                  launches that have the GPU to themselves); `traffic` is the HBM bytes per launch from the committed
-                  PMC passes (profiles/r01_pmc_summary.json).
+Also on the JSON line (SURVEY.md 8d):
+  roofline     -- the dominant kernel family (k_spconv*, csrc/spconv.hip): algorithmic bytes of every launch
+                  ((V_in*C_in + V_out*C_out)*b + K*C_in*C_out*b + 8*P, true channel counts, no residual term) divided by
+                  that launch's duration, measured with HIP events on the launching stream in an instrumented pass over
+                  the same steps in the same in-flight mode; `by_level` splits the figure per tensor stride (the
+                  stride-1/2 levels carry 83 % of the activation bytes); `one_scene_in_flight` holds the same figures for
+                  launches that have the GPU to themselves; `traffic` is the HBM bytes per launch from the committed PMC
+                  passes (profiles/*_pmc_summary.json).
+  stages_ms    -- per-stage wall time of one scene alone on the GPU (device synchronised at the stage boundaries).
+  grouping     -- points grouped per forward, microseconds and points/s of the grouping stage.
+  tta3         -- the same path on the reference's 3-rotated-copies eval batch (dataset_preprocess.py:324).
   cpu_baseline -- the CPU oracle (oracle/, a restatement: the reference's own CPU path cannot be installed) timed on
-                  the host cores of rank 0 at N=1 on one full scene of the same workload.
+                  the host cores of rank 0 at N=1 on full scenes of the same workload, median of 3.
+  phases_s     -- wall clock of the phases of this run (build, warm-up, timed blocks, probes, TTA leg, CPU baseline).
 """
 import argparse
 import json
@@ -36,6 +44,7 @@ import sys
 import threading
 import time
 
+T_START = time.perf_counter()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -48,6 +57,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+PMC_SUMMARIES = ("r02_pmc_summary.json", "r01_pmc_summary.json")   # newest first
 
 
 WORKLOADS = {
@@ -57,21 +67,29 @@ WORKLOADS = {
 }
 
 
-def build_workload(rank, copies, dtype, device, workload="c2"):
-    from pbnet_amd import synth
+def build_model(device):
     from pbnet_amd.config import get_config
     from pbnet_amd.network.PBNet import PBNet
     cfg = get_config(test=True)
     torch.manual_seed(22)  # /root/reference/config/config.py:15
-    model = PBNet(cfg).to(device).eval()
+    return cfg, PBNet(cfg).to(device).eval()
+
+
+def build_scene(copies, dtype, device, workload="c2"):
+    from pbnet_amd import synth
     # weak scaling: per-GPU work is fixed, so every rank holds its own copy of the SAME scene (other seeds of the
     # generator give scenes of 148-161 k voxels, and the slowest rank would set the time of the whole job)
-    w = dict(WORKLOADS[workload])
-    batch, teacher, info = synth.make_val_batch(copies=copies, **w)
+    batch, teacher, info = synth.make_val_batch(copies=copies, **WORKLOADS[workload])
     b = {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
     b["feat_voxel"] = b["feat_voxel"].to(dtype)
     t = {k: torch.from_numpy(v).to(device) for k, v in teacher.items()}
-    return cfg, model, b, t, info, (batch, teacher)
+    return b, t, info, (batch, teacher)
+
+
+def build_workload(rank, copies, dtype, device, workload="c2"):
+    cfg, model = build_model(device)
+    b, t, info, raw = build_scene(copies, dtype, device, workload)
+    return cfg, model, b, t, info, raw
 
 
 def one_step(model, b, t):
@@ -80,17 +98,19 @@ def one_step(model, b, t):
 
 
 class ConvProbe(object):
-    """Instrumented pass over the same steps: HIP events on the launching stream around every k_spconv launch
-    (per-op events inside the native U-Net executor, pbn_unet_forward_timed; torch.cuda.Event around the few launches
-    issued from Python) plus each launch's algorithmic bytes / flops."""
+    """Instrumented pass over the same steps: HIP events on the launching stream around every convolution op (per-op
+    events inside the native U-Net executor, pbn_unet_forward_timed; torch.cuda.Event around the few launches issued
+    from Python) plus each op's algorithmic bytes / flops."""
 
     K_OF_KIND = {0: 1, 1: 27, 2: 125, 3: 8, 4: 8}
 
     def __init__(self):
         self.ms = 0.0
-        self.nbytes = 0
+        self.nbytes = 0          # strict SURVEY 8d bytes: true channel counts, no residual term
+        self.nbytes_r1 = 0       # round-1 accounting (8-padded C_in, + residual read): kept for comparison
         self.flops = 0
         self.launches = 0
+        self.levels = {}         # tensor stride of the output level -> [launches, ms, bytes, flops]
         self.py_records = []
         self.lock = threading.Lock()
 
@@ -108,7 +128,6 @@ class ConvProbe(object):
 
     def _unet_sink(self, plan, rows, cm, esz, op_ms):
         pair_cache = {}
-        widths = [plan["bufs"][i].width for i in range(plan["n_bufs"])]
         for i in range(plan["n_ops"]):
             op = plan["ops"][i]
             key = (op.map_kind, op.level_in, op.level_out)
@@ -116,16 +135,21 @@ class ConvProbe(object):
                 pair_cache[key] = self._pairs(cm, op.map_kind, op.level_in, op.level_out, rows)
             pairs = pair_cache[key]
             k = self.K_OF_KIND[op.map_kind]
-            cin = op.vpo * (16 // esz)
-            cout = op.cout_p
+            cin_t, cout_t = plan["true_io"][i]
+            cin_p, cout_p = op.vpo * (16 // esz), op.cout_p
             v_in, v_out = rows[op.level_in], rows[op.level_out]
-            nbytes = (v_in * cin + v_out * cout) * esz + k * cin * cout * esz + (8 * pairs if op.map_kind else 0)
+            nbytes = (v_in * cin_t + v_out * cout_t) * esz + k * cin_t * cout_t * esz + (8 * pairs if op.map_kind else 0)
+            r1 = (v_in * cin_p + v_out * cout_p) * esz + k * cin_p * cout_p * esz + (8 * pairs if op.map_kind else 0)
             if op.res_buf >= 0:
-                nbytes += v_out * cout * esz
+                r1 += v_out * cout_p * esz
+            flops = 2 * pairs * cin_t * cout_t
             self.nbytes += nbytes
-            self.flops += 2 * pairs * cin * cout
+            self.nbytes_r1 += r1
+            self.flops += flops
             self.ms += op_ms[i]
             self.launches += 1
+            lv = self.levels.setdefault(1 << op.level_out, [0, 0.0, 0, 0])
+            lv[0] += 1; lv[1] += op_ms[i]; lv[2] += nbytes; lv[3] += flops
 
     def install(self):
         from pbnet_amd.MinkowskiEngine import conv as C
@@ -163,27 +187,30 @@ class ConvProbe(object):
         for e0, e1, nbytes, flops in self.py_records:
             self.ms += e0.elapsed_time(e1)
             self.nbytes += nbytes
+            self.nbytes_r1 += nbytes
             self.flops += flops
             self.launches += 1
         return self.launches, self.ms, self.nbytes, self.flops
 
 
 def pmc_traffic(args):
-    """HBM bytes per k_spconv launch from the committed PMC summary (profiles/r01_pmc_summary.json: two rocprofv3 --pmc
-    passes over this same command line, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).
-    Counters cannot be read from inside the process, so the number is only reported for the configuration it was
-    collected on (default workload, bf16, 1 copy); anything else -> null."""
+    """HBM bytes per convolution launch from the newest committed PMC summary (two rocprofv3 --pmc passes over this
+    same command line, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).  Counters cannot
+    be read from inside the process, so the number is only reported for the configuration it was collected on (default
+    workload, bf16, 1 copy); anything else -> null."""
     if args.copies != 1 or args.dtype != "bf16" or args.workload != "c2":
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-            return int(json.load(f)["k_spconv_traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+        return None, None
+    for name in PMC_SUMMARIES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return int(json.load(f)["k_spconv_traffic_bytes_per_launch"]), "profiles/" + name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
-def cpu_baseline(cfg, model, raw):
-    """Oracle (kind "port") on the host cores: one full scene of the same workload."""
+def cpu_baseline(cfg, model, raw, runs=3):
+    """Oracle (kind "port") on the host cores: full scenes of the same workload, median of `runs`."""
     from oracle import pbnet_ref
     batch, teacher = raw
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -192,78 +219,55 @@ def cpu_baseline(cfg, model, raw):
     from pbnet_amd.hostinfo import usable_cores
     cores = usable_cores()
     torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    s1 = pbnet_ref.backbone_stage(sd, tb["feat_voxel"], tb["xyz_voxel"], tb["v2p_index"])
-    s1["sem_pred_score_p"] = tt["sem_score"]
-    s1["sem_pred_score_sfp"] = torch.softmax(tt["sem_score"], 1)
-    s1["offset_pred_p"] = tt["offset"]
-    s1["sem_pred_p"] = tt["sem_score"].max(1)[1]
-    pbnet_ref.cluster_stage(sd, cfg, s1, tb["xyz_original"], None, "test")
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        s1 = pbnet_ref.backbone_stage(sd, tb["feat_voxel"], tb["xyz_voxel"], tb["v2p_index"])
+        s1["sem_pred_score_p"] = tt["sem_score"]
+        s1["sem_pred_score_sfp"] = torch.softmax(tt["sem_score"], 1)
+        s1["offset_pred_p"] = tt["offset"]
+        s1["sem_pred_p"] = tt["sem_score"].max(1)[1]
+        pbnet_ref.cluster_stage(sd, cfg, s1, tb["xyz_original"], None, "test")
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     return {"value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": "1 full scene of the same workload (fp32 torch gather-mm-index_add backbone on all host cores + "
-                      "single-thread C grouping), %.1f s" % dt}
+            "sample": "%d full scenes of the same workload, median (fp32 torch gather-mm-index_add backbone on all host "
+                      "cores + single-thread C grouping): %s s" % (runs, ", ".join("%.1f" % t for t in times))}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--copies", type=int, default=1, help="rotated copies per scene (reference eval uses 3: TTA)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=4,
-                    help="scenes in flight per GPU (one host thread + HIP stream each); 1 = the reference's loop")
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
-                    help="c2 = BASELINE configs[1] (default, the metric); c4 = configs[3], the dense 1 cm stress scene")
-    args = ap.parse_args()
+def grouped_points(raw):
+    """Points that enter the grouping stage: the classes that pass the population gate (PBNet.py:156)."""
+    from pbnet_amd.network.PBNet import COUNT_MEAN
+    sem = raw[1]["sem_score"].argmax(1)
+    cnt = np.bincount(sem, minlength=20)
+    return int(sum(int(cnt[c]) for c in range(2, 20) if not (float(cnt[c]) < np.float32(COUNT_MEAN[c]) * np.float32(0.05))))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
-    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
-    cfg, model, b, t, info, raw = build_workload(rank, args.copies, dtype, device, args.workload)
+class Runner(object):
+    """K steps taken round-robin by `inflight` host threads, one HIP stream each (inflight 1: a plain loop)."""
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def __init__(self, model, b, t, inflight, device):
+        self.model, self.b, self.t, self.inflight, self.device = model, b, t, inflight, device
+        self.streams = [torch.cuda.Stream(device) for _ in range(inflight)] if inflight > 1 else [None]
+        self.last = [None] * len(self.streams)
 
-    # `--inflight M`: M host threads, each with its own HIP stream, take the K steps round-robin (scenes are independent
-    # units, eval_map.py:48-50); kernels of different scenes overlap on the device and one scene's host read-backs hide
-    # behind another's kernels.  M = 1 is the reference's one-scene-at-a-time loop.
-    streams = [torch.cuda.Stream(device) for _ in range(args.inflight)] if args.inflight > 1 else [None]
-    last = [None] * len(streams)
-
-    def run_steps(n):
-        if args.inflight == 1:
+    def run(self, n):
+        if self.inflight == 1:
             for _ in range(n):
-                last[0] = one_step(model, b, t)
+                self.last[0] = one_step(self.model, self.b, self.t)
             return
         errors = []
 
         def worker(i):
             try:
-                torch.cuda.set_device(device)
-                with torch.cuda.stream(streams[i]):
-                    for _ in range(i, n, args.inflight):
-                        last[i] = one_step(model, b, t)
-                    streams[i].synchronize()
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(self.streams[i]):
+                    for _ in range(i, n, self.inflight):
+                        self.last[i] = one_step(self.model, self.b, self.t)
+                    self.streams[i].synchronize()
             except BaseException as e:      # surfaced below: a failed worker must fail the bench
                 errors.append(e)
-        threads = [threading.Thread(target=worker, args=(i,)) for i in range(args.inflight)]
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(self.inflight)]
         for th in threads:
             th.start()
         for th in threads:
@@ -271,45 +275,142 @@ def main():
         if errors:
             raise errors[0]
 
+    def result(self):
+        return next(r for r in self.last if r is not None)
+
+
+def init_process_group(world, rank, device):
+    """RCCL process group (backend "nccl" is RCCL on ROCm), also at world size 1: init + one all-reduce + barrier, so the
+    multi-GPU code path has run on this box before an 8-GPU node ever sees it.  At N = 1 a failure is reported on the JSON
+    line instead of failing the run (the single-GPU metric does not need the group)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1 and "MASTER_PORT" not in os.environ:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        s.close()
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        probe = torch.full((1024,), float(rank + 1), device=device)
+        dist.all_reduce(probe)
+        dist.barrier()
+        torch.cuda.synchronize()
+        want = world * (world + 1) / 2
+        if float(probe[0]) != want:
+            raise RuntimeError("all-reduce returned %r, expected %r" % (float(probe[0]), want))
+        return dist, "ok (backend nccl = RCCL, world %d: init, all-reduce, barrier)" % world
+    except Exception as e:  # noqa: BLE001
+        if world > 1:
+            raise
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        return None, "FAILED at world 1: %s: %s" % (type(e).__name__, str(e)[:200])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median block is reported")
+    ap.add_argument("--copies", type=int, default=1, help="rotated copies per scene (reference eval uses 3: TTA)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stage breakdown, the TTA leg and the CPU baseline")
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="scenes in flight per GPU (one host thread + HIP stream each); 1 = the reference's loop")
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
+                    help="c2 = BASELINE configs[1] (default, the metric); c4 = configs[3], the dense 1 cm stress scene")
+    args = ap.parse_args()
+    phases = {}
+    t_phase = [time.perf_counter()]
+
+    def phase(name):
+        now = time.perf_counter()
+        phases[name] = round(phases.get(name, 0.0) + now - t_phase[0], 2)
+        t_phase[0] = now
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    phases["import_torch"] = round(time.perf_counter() - T_START, 2)
+    t_phase[0] = time.perf_counter()
+    dist, rccl_status = init_process_group(world, rank, device)
+    phase("rccl_init")
+
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    cfg, model, b, t, info, raw = build_workload(rank, args.copies, dtype, device, args.workload)
+    phase("build_workload")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    runner = Runner(model, b, t, args.inflight, device)
     one_step(model, b, t)                   # fills the weight / threshold caches once, on one thread
     torch.cuda.synchronize()
-    run_steps(args.inflight)                # every stream allocates its scratch (split-K slabs, allocator pools) once
-    run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ret = next(r for r in last if r is not None)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    runner.run(args.inflight)               # every stream allocates its scratch and allocator pools once
+    phase("first_steps")
+    runner.run(args.warmup)
+    blocks = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        runner.run(args.steps)              # EXACTLY K steps
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        blocks.append(el)
+    phase("warmup_and_timed_blocks")
+    elapsed = float(np.median(blocks))
+    rate = lambda e: world * args.steps / e
+    ret = runner.result()
     n_prop = int(ret["proposals"][1].shape[0] - 1)
 
-    roof = None
-    cpu = None
-    single_ms = None
+    roof = cpu = single_ms = stages = grouping = tta = None
     if rank == 0:
         n_probe = max(2, min(args.steps, 5)) * args.inflight
 
-        def probe_leg(runner, n):
+        def probe_leg(run, n):
             probe = ConvProbe()
             probe.install()
-            runner(n)
+            run(n)
             n_launch, t_ms, nbytes, flops = probe.summary()
             probe.remove()
             achieved = nbytes / (t_ms * 1e-3) / 1e9
-            return {"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "launches_per_step": n_launch // n, "avg_launch_us": round(t_ms * 1e3 / n_launch, 2),
-                    "algorithmic_bytes_per_launch": int(nbytes / n_launch),
-                    "achieved_tflops": round(flops / (t_ms * 1e-3) / 1e12, 2)}
+            leg = {"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                   "launches_per_step": n_launch // n, "avg_launch_us": round(t_ms * 1e3 / n_launch, 2),
+                   "algorithmic_bytes_per_launch": int(nbytes / n_launch),
+                   "algorithmic_bytes_per_launch_r01_accounting": int(probe.nbytes_r1 / n_launch),
+                   "achieved_tflops": round(flops / (t_ms * 1e-3) / 1e12, 2), "by_level": []}
+            for stride in sorted(probe.levels):
+                c, ms, by, fl = probe.levels[stride]
+                gbs = by / (ms * 1e-3) / 1e9
+                leg["by_level"].append({"tensor_stride": stride, "launches_per_step": c // n, "avg_launch_us": round(ms * 1e3 / c, 2),
+                                        "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                        "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2)})
+            return leg
 
         # the launches are timed in the mode the timed region ran in: with several scenes in flight a launch shares the
         # CUs with the other streams' kernels, so its own duration grows while the whole-job rate rises
-        leg = probe_leg(run_steps, n_probe)
+        leg = probe_leg(runner.run, n_probe)
+        traffic, traffic_src = pmc_traffic(args)
         roof = {"bound": "hbm", "achieved": leg.pop("achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": leg.pop("frac"), "traffic": pmc_traffic(args), "kernel": "k_spconv"}
+                "frac": leg.pop("frac"), "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_spconv*"}
         roof.update(leg)
         # the same bytes against the wall clock of the whole job (SURVEY.md 8d's path-level form, convolution bytes only):
         # what the GPU sustains across all in-flight scenes, non-convolution stages included in the time
@@ -317,25 +418,83 @@ def main():
         path_gbs = conv_bytes_per_scene * args.steps / elapsed / 1e9
         roof["path_level"] = {"conv_algorithmic_bytes_per_scene": conv_bytes_per_scene, "achieved": round(path_gbs, 1),
                               "frac": round(path_gbs / HBM_PEAK_GBS, 4)}
+
+        def one_at_a_time(n):
+            for _ in range(n):
+                one_step(model, b, t)
         if args.inflight > 1:
-            def one_at_a_time(n):
-                for _ in range(n):
-                    one_step(model, b, t)
             roof["one_scene_in_flight"] = probe_leg(one_at_a_time, max(2, min(args.steps, 5)))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one_at_a_time(10)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t1) / 10 * 1e3
+        phase("roofline_probes")
+        if not args.no_extras:
+            # per-stage wall time, one scene alone on the GPU, device synchronised at every stage boundary
+            from pbnet_amd import prof
+            prof.reset()
+            prof.enable(True)
+            one_at_a_time(5)
+            prof.enable(False)
+            rep = prof.report()
+            g = lambda *names: round(sum(rep[k][0] for k in names if k in rep), 3)
+            stages = {"coords_and_maps_backbone": g("a3_coords"), "unet_backbone_34C": g("a4_unet"),
+                      "heads_and_gathers": g("a5_heads_gather"), "class_selection": g("a6_select"),
+                      "grouping": g("a7_16_grouping"), "local_scene_plan_host": g("a17_plan"),
+                      "local_scene_rows": g("a17_gather"), "coords_and_maps_mask": g("a18_mask_coords"),
+                      "unet_mask_14A": g("a18_mask_unet"), "proposals": g("a19_proposals"),
+                      "coords_and_maps_score": g("a20_score_coords"), "unet_score_34C": g("a20_score_unet"),
+                      "pool_and_score_head": g("a20_pool_head")}
+            stages["sum"] = round(sum(stages.values()), 3)
+            # voxelisation happens before the path (inputs arrive voxelised); timed here for SURVEY 8d's list
+            from pbnet_amd import loader_ops
+            xyz = [b["xyz_original"].double()]
+            ft = [torch.zeros(b["xyz_original"].shape[0], 6, device=device)]
+            loader_ops.voxelize_batch(xyz, ft, WORKLOADS[args.workload]["voxel"])
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            one_at_a_time(10)
+            tv = time.perf_counter()
+            for _ in range(5):
+                loader_ops.voxelize_batch(xyz, ft, WORKLOADS[args.workload]["voxel"])
             torch.cuda.synchronize()
-            single_ms = (time.perf_counter() - t1) / 10 * 1e3
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(cfg, model, raw)
+            stages["voxelise_outside_the_metric"] = round((time.perf_counter() - tv) / 5 * 1e3, 3)
+            m = grouped_points(raw)
+            grouping = {"points_grouped_per_forward": m, "us": round(stages["grouping"] * 1e3, 1),
+                        "points_per_s": round(m / (stages["grouping"] * 1e-3), 0) if stages["grouping"] > 0 else None,
+                        "note": "stage wall time incl. its read-back of the cluster table, one scene alone on the GPU"}
+            phase("stage_breakdown")
+            if args.copies == 1 and world == 1:
+                # the reference's eval batch: 3 rotated copies of the scene per forward (dataset_preprocess.py:324)
+                b3, t3, info3, _ = build_scene(3, dtype, device, args.workload)
+                r3 = Runner(model, b3, t3, args.inflight, device)
+                r3.run(args.inflight)
+                r3.run(max(2, args.warmup // 2))
+                k3 = max(args.inflight, args.steps // 3)
+                bl3 = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    r3.run(k3)
+                    torch.cuda.synchronize()
+                    bl3.append(time.perf_counter() - t0)
+                e3 = float(np.median(bl3))
+                tta = {"value": round(k3 / e3, 3), "unit": "scenes/s (1 scene = 3 rotated copies per forward)",
+                       "copies_per_s": round(3 * k3 / e3, 1), "ms_per_step": round(e3 / k3 * 1e3, 3), "steps": k3,
+                       "points_per_step": info3["n_points"], "voxels_per_step": info3["n_voxels"],
+                       "proposals_per_step": int(r3.result()["proposals"][1].shape[0] - 1)}
+                del b3, t3, r3
+                phase("tta3_leg")
+            if world == 1 and not args.no_cpu_baseline:
+                cpu = cpu_baseline(cfg, model, raw)
+                phase("cpu_baseline")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        phases["total"] = round(time.perf_counter() - T_START, 2)
         line = {
             "metric": "scenes/sec fwd+cluster (ScanNet ~150k pts/scene)",
-            "value": round(world * args.steps / elapsed, 3),
+            "value": round(rate(elapsed), 3),
             "unit": "scenes/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -347,6 +506,9 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic room scene (pbnet_amd/synth.py), random-init weights (seed 22), teacher-forced "
                     "semantic/offset head outputs",
+            "timed_blocks": {"n": len(blocks), "statistic": "median", "value_p10": round(rate(float(np.percentile(blocks, 90))), 3),
+                             "value_p90": round(rate(float(np.percentile(blocks, 10))), 3),
+                             "ms_per_step_all": [round(e / args.steps * 1e3, 3) for e in blocks]},
             "config": {"workload": "%s: 1 scene, %d pts, %d voxels @%gcm, %d rotated cop%s, full "
                                    "PBNet.forward (MinkUNet34C + grouping + MinkUNet14A mask + MinkUNet34C score)"
                                    % ("configs[1]" if args.workload == "c2" else "configs[3]",
@@ -357,12 +519,24 @@ def main():
                        "proposals_per_step": n_prop, "scenes_in_flight_per_gpu": args.inflight,
                        "one_scene_in_flight_ms_per_scene": None if single_ms is None else round(single_ms, 3),
                        "parallelism": "scenes sharded over GPUs, %d in flight per GPU (host thread + HIP stream each), "
-                                      "no data-path collective" % args.inflight},
+                                      "no data-path collective" % args.inflight,
+                       "rccl": rccl_status},
             "roofline": roof,
         }
+        if stages is not None:
+            line["stages_ms"] = stages
+            line["grouping"] = grouping
+        if tta is not None:
+            line["tta3"] = tta
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line))
+        line["phases_s"] = phases
+        # RCCL prints its version banner through C stdio, which is flushed at exit when stdout is a file: flush it now so
+        # that the JSON line is the LAST line of stdout
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

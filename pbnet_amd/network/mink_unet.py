@@ -153,7 +153,7 @@ class MinkUNet(nn.Module):
         Buffer 0 is the input slab; levels 0..4 are tensor strides 1..16."""
         from .. import _native as N
         P = self.PLANES
-        keep, ops, bufs = [], [], [(0, 0)]
+        keep, ops, bufs, true_io = [], [], [(0, 0)], []
         skip_c = (INIT_DIM, P[0], P[1], P[2])
         up_c = (P[7], P[6], P[5], P[4])
 
@@ -169,6 +169,7 @@ class MinkUNet(nn.Module):
                 scale = None
                 shift = _pad_vec(conv.bias.detach(), cout_p, 0.0) if conv.bias is not None else None
             keep.extend([w, scale, shift])
+            true_io.append((int(conv.kernel.shape[-2]), int(conv.kernel.shape[-1])))   # un-padded (C_in, C_out)
             if out is None:
                 out = (new_buf(lout, cout_p), 0)
             op = N.UnetOp()
@@ -209,7 +210,7 @@ class MinkUNet(nn.Module):
         ops_arr = (N.UnetOp * len(ops))(*ops)
         bufs_arr = (N.UnetBuf * len(bufs))(*[N.UnetBuf(lv, w) for lv, w in bufs])
         return dict(ops=ops_arr, n_ops=len(ops), bufs=bufs_arr, n_bufs=len(bufs), out_buf=final[0], cin_p=cin_p,
-                    out_width=bufs[final[0]][1], keep=keep)
+                    out_width=bufs[final[0]][1], keep=keep, true_io=true_io)
 
     def _forget_state_tensors(self):
         self.__dict__.pop("_state_tensors", None)

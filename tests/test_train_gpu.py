@@ -77,6 +77,47 @@ def test_convolution_gradients(kind):
         assert _rel(b_dev.grad.cpu().view(-1), br.grad.view(-1)) < 1e-5, "bias gradient"
 
 
+@pytest.mark.parametrize("kind", ["k3", "k5", "down", "up", "1x1"])
+def test_convolution_gradients_bf16(kind):
+    """The same layer kinds with bf16 slabs (BASELINE configs[2]): forward, input gradient (dgrad on k_spconv) and
+    weight gradient against fp32 autograd through the oracle ON THE bf16-ROUNDED OPERANDS, so that what is measured is
+    the kernels' own error (fp32 accumulation of bf16 products, one rounding of the result), not the input rounding."""
+    coords = _coords()
+    cm_ref = R.CoordinateManager(coords)
+    torch.manual_seed(8)
+    cin, cout = (6, 32) if kind == "k5" else (32, 48)
+    n1, n2 = len(coords), cm_ref.get_coords(2).shape[0]
+    if kind in ("k3", "k5", "1x1"):
+        k = {"k3": 3, "k5": 5, "1x1": 1}[kind]
+        mod = ME.MinkowskiConvolution(cin, cout, kernel_size=k, dimension=3)
+        n_in, n_out, in_stride = n1, n1, 1
+        ref = lambda x, w: R.conv(x, w, None if k == 1 else cm_ref.get_map(1, 1, k), n1)
+    elif kind == "down":
+        mod = ME.MinkowskiConvolution(cin, cout, kernel_size=2, stride=2, dimension=3)
+        n_in, n_out, in_stride = n1, n2, 1
+        ref = lambda x, w: R.conv(x, w, cm_ref.get_map(1, 2, 2), n2)
+    else:
+        mod = ME.MinkowskiConvolutionTranspose(cin, cout, kernel_size=2, stride=2, dimension=3)
+        n_in, n_out, in_stride = n2, n1, 2
+        ref = lambda x, w: R.conv_transpose(x, w, cm_ref.get_map(1, 2, 2), n1)
+    q = lambda t: t.to(torch.bfloat16).float()
+    x0, gy = q(torch.randn(n_in, cin)), q(torch.randn(n_out, cout))
+    xr = x0.clone().requires_grad_(True)
+    wr = q(mod.kernel.detach()).clone().requires_grad_(True)
+    yr = ref(xr, wr)
+    (yr * gy).sum().backward()
+    mod = mod.to(DEV)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(DEV))
+    xd = x0.to(DEV).to(torch.bfloat16).requires_grad_(True)
+    yd = mod(ME.SparseTensor(xd, coordinate_manager=cm, tensor_stride=in_stride)).F
+    assert yd.dtype == torch.bfloat16
+    r_y = _rel(yd.detach().float().cpu(), yr.detach())
+    (yd * gy.to(DEV).to(torch.bfloat16)).sum().backward()
+    r_x, r_w = _rel(xd.grad.float().cpu(), xr.grad), _rel(mod.kernel.grad.float().cpu(), wr.grad)
+    print("%s bf16: forward rel %.2e, dgrad rel %.2e, wgrad rel %.2e" % (kind, r_y, r_x, r_w))
+    assert r_y < 4e-3 and r_x < 4e-3 and r_w < 4e-3      # one bf16 rounding of the result: 2^-9 = 2e-3 per element
+
+
 def test_unet_training_step_gradients():
     """MinkUNet14A in train mode: loss.backward() through every layer kind; gradients vs oracle autograd."""
     coords = _coords(seed=52)
