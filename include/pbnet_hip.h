@@ -150,7 +150,11 @@ int pbn_up_table(const int32_t* parent_row, const int32_t* child_k, const int32_
  *  scale/shift [cout_padded] f32 or NULL (folded eval-mode BatchNorm / bias)
  *  residual  [*, ld_res] T or NULL;  relu != 0 applies max(.,0);  out_feat [*, ld_out] T, cout_padded columns written
  *  dtype     PBN_F32 (v_mfma_f32_16x16x4_f32, exact fp32: the parity configuration), PBN_BF16, PBN_F16
- *  rows_per_wave 16, 32 or 0 (auto).
+ *  rows_per_wave 0 = automatic choice of kernel family and tile (production); 16 / 32 = the workgroup-tile family of
+ *                csrc/spconv.hip with that many rows per wave; >= 100 = the wave-autonomous family of
+ *                csrc/spconv_wave.hip in configuration 1000*ksplit + 100*NF + NT (NF 16-row fragments per wave, NT
+ *                16-channel tiles per workgroup; PBN_ERR_UNSUPPORTED for a combination that is not built) -- the explicit
+ *                values exist for tests and tuning.
  *  workspace     optional scratch (16-byte aligned) for split-K launches: when the row count is too small to fill the
  *                256 CUs the reduction axis is cut into slices whose fp32 partial sums go through this buffer and are
  *                combined in a fixed order by a second kernel; NULL / too small => single-pass launch.
@@ -241,6 +245,17 @@ int pbn_rulebook_pair_blocks(int n);
 int pbn_rulebook_pair_counts(const int32_t* nbr, int n, int n_offsets, int32_t* table, int32_t* totals, pbn_stream_t stream);
 int pbn_rulebook_pair_fill(const int32_t* nbr, int n, int n_offsets, const int32_t* table, const int32_t* seg_start, int seg,
                            int n_segments, int64_t* in_idx, int64_t* out_idx, int64_t* seg_offset, pbn_stream_t stream);
+
+/* Weight gradient of the sparse convolution on the matrix cores (csrc/wgrad.hip), ME's convolution backward w.r.t. the
+ * kernel (reached from train.py:57 loss.backward()):  dw[k, ci, co] = sum over the pairs (i, o) of offset k of
+ * x[i, ci] * g[o, co].  in_idx / out_idx / seg_begin: the lists of pbn_rulebook_pair_fill, seg_begin int32[K+1] = first
+ * `segment`-pair segment of every offset; all three NULL = identity pairs (1x1 convolution / linear layer; n_offsets 1,
+ * n_pairs_total rows).  x [*, ld_x], g [*, ld_g] of `dtype` (widened exactly), dw f32[K, cin, cout], any cin / cout.
+ * fp32 accumulation in a fixed order (deterministic).  workspace: pbn_spconv_wgrad_workspace_bytes (pair splits). */
+size_t pbn_spconv_wgrad_workspace_bytes(int n_offsets, int cin, int cout);
+int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g, int dtype, const int64_t* in_idx,
+                     const int64_t* out_idx, const int32_t* seg_begin, int segment, int n_pairs_total, int n_offsets,
+                     int cin, int cout, float* dw, void* workspace, size_t workspace_bytes, pbn_stream_t stream);
 
 /* pbn_mlp_rows -- the two-layer heads of network/PBNet.py:43-82 in eval mode, one launch per head:
  *   out[i, 0:n_out] = act( W2 . prelu( (W1 . x) * scale + shift ) + b2 ),   x = in[row(i), 0:channels],

@@ -135,7 +135,6 @@ def _pad_vec(v, cout_p, fill):
     return out
 
 
-WGRAD_CHUNK_BYTES = 192 << 20
 WGRAD_PAIR_SEGMENT = 4096         # rule pairs per batched-GEMM segment of the compacted weight gradient
 
 
@@ -167,14 +166,16 @@ def rulebook_pairs(nbr, segment=WGRAD_PAIR_SEGMENT):
     N.check(lib.pbn_rulebook_pair_counts(N.ptr(nbr), v, k, N.ptr(table), N.ptr(totals), st), "pbn_rulebook_pair_counts")
     cnt = totals.cpu().numpy().astype(np.int64)                                  # the one read-back
     segs = (cnt + segment - 1) // segment
-    seg_start = np.concatenate([[0], np.cumsum(segs)[:-1]]).astype(np.int32)
+    seg_begin = np.concatenate([[0], np.cumsum(segs)]).astype(np.int32)        # [K+1]
+    seg_start = seg_begin[:-1]
     n_seg = int(segs.sum())
     in_idx = torch.empty(n_seg * segment, dtype=torch.int64, device=dev)
     out_idx = torch.empty(n_seg * segment, dtype=torch.int64, device=dev)
     seg_offset = torch.empty(n_seg, dtype=torch.int64, device=dev)
-    N.check(lib.pbn_rulebook_pair_fill(N.ptr(nbr), v, k, N.ptr(table), N.ptr(torch.from_numpy(seg_start).to(dev)), segment,
+    seg_begin_d = torch.from_numpy(seg_begin).to(dev)
+    N.check(lib.pbn_rulebook_pair_fill(N.ptr(nbr), v, k, N.ptr(table), N.ptr(seg_begin_d), segment,
                                        n_seg, N.ptr(in_idx), N.ptr(out_idx), N.ptr(seg_offset), st), "pbn_rulebook_pair_fill")
-    hit = (in_idx, out_idx, seg_offset, n_seg, segment)
+    hit = (in_idx, out_idx, seg_offset, n_seg, segment, seg_begin_d)
     try:
         nbr._pbn_pairs = hit
     except AttributeError:
@@ -182,72 +183,38 @@ def rulebook_pairs(nbr, segment=WGRAD_PAIR_SEGMENT):
     return hit[:4]
 
 
-def _bmm_f32(a, b):
-    """Batched GEMM with an fp32 result (rocBLAS accumulates in fp32; keep it when this torch can return it)."""
-    if a.dtype == torch.float32:
-        return torch.bmm(a, b)
-    global _BMM_OUT_DTYPE
-    if _BMM_OUT_DTYPE is None:
-        try:
-            torch.bmm(a[:1, :1, :1], b[:1, :1, :1], out_dtype=torch.float32)
-            _BMM_OUT_DTYPE = True
-        except (TypeError, RuntimeError):
-            _BMM_OUT_DTYPE = False
-    return torch.bmm(a, b, out_dtype=torch.float32) if _BMM_OUT_DTYPE else torch.bmm(a, b).float()
+_WGRAD_WS = StreamScratch()
 
 
-_BMM_OUT_DTYPE = None
-
-
-def _wgrad_compact(f, g, nbr, cin, cout):
-    """dW from the compacted pair lists: both operands gathered pair by pair (no rows for absent neighbours: a centred
-    3x3x3 map is ~26 % populated), one batched GEMM over the segments (fp32 accumulation), segments summed per offset."""
-    in_idx, out_idx, seg_offset, n_seg = rulebook_pairs(nbr)
-    c = WGRAD_PAIR_SEGMENT
-    dw = torch.zeros(nbr.shape[1], cin, cout, dtype=torch.float32, device=f.device)
-    seg_per_pass = max(1, WGRAD_CHUNK_BYTES // (c * (cin + cout) * f.element_size()))
-    for s0 in range(0, n_seg, seg_per_pass):
-        s1 = min(n_seg, s0 + seg_per_pass)
-        x = _gather_rows(f, in_idx[s0 * c:s1 * c]).view(s1 - s0, c, cin)
-        y = _gather_rows(g, out_idx[s0 * c:s1 * c]).view(s1 - s0, c, cout)
-        dw.index_add_(0, seg_offset[s0:s1], _bmm_f32(x.transpose(1, 2), y))
+def wgrad_native(feats, grad_out, nbr, cin, cout):
+    """dW[k] = sum over the rule pairs (i, o) of offset k of feats[i]^T grad_out[o] on the matrix cores
+    (pbn_spconv_wgrad, csrc/wgrad.hip): pair lists from pbn_rulebook_pair_* (cached per map; every layer of a level shares
+    them), operands read in place (no gathered copies), fixed summation order, fp32 result [K, cin, cout].
+    nbr None = identity pairs (1x1 convolution / linear layer)."""
+    N.require_cuda(feats, grad_out)
+    assert feats.dtype == grad_out.dtype and feats.stride(1) == 1 and grad_out.stride(1) == 1
+    dev = feats.device
+    lib = N.lib()
+    if nbr is None:
+        k, in_idx, out_idx, seg_begin, n_pairs = 1, None, None, None, int(feats.shape[0])
+    else:
+        assert nbr.is_contiguous()
+        k = int(nbr.shape[1])
+        rulebook_pairs(nbr)
+        in_idx, out_idx, _, n_seg, segment, seg_begin = nbr._pbn_pairs
+        n_pairs = n_seg * segment
+    dw = torch.empty(k, cin, cout, dtype=torch.float32, device=dev)
+    ws = _WGRAD_WS.get(dev, int(lib.pbn_spconv_wgrad_workspace_bytes(k, cin, cout)))
+    rc = lib.pbn_spconv_wgrad(N.c_vp(feats.data_ptr()), feats.stride(0), N.c_vp(grad_out.data_ptr()), grad_out.stride(0),
+                              _DT[feats.dtype], N.ptr(in_idx), N.ptr(out_idx), N.ptr(seg_begin),
+                              WGRAD_PAIR_SEGMENT if nbr is not None else 0, n_pairs, k, int(cin), int(cout), N.ptr(dw),
+                              N.c_vp(ws.data_ptr()), ws.numel(), N.current_stream())
+    N.check(rc, "pbn_spconv_wgrad")
     return dw
 
 
 def _wgrad(feats, grad_out, nbr, cin, cout):
-    """dW[k] = sum over rule pairs (i, o) at offset k of feats[i]^T grad_out[o].  Rows of both operands are gathered
-    through the offset-major pair lists (pbn_rulebook_pair_*) and contracted by one batched library GEMM (rocBLAS through
-    torch.bmm -- the contraction itself has no sparse structure left once the rows are gathered); operands whose rows
-    are not whole 16-byte vectors (the 6-channel stem) take the dense-slab form below.  fp32 result."""
-    if nbr is None:
-        return (feats[:, :cin].t() @ grad_out[:, :cout]).float().unsqueeze(0)
-    v, k = nbr.shape
-    es = feats.element_size()
-    if (cin * es) % 16 == 0 and (cout * es) % 16 == 0 and feats.stride(1) == 1 and (feats.stride(0) * es) % 16 == 0 \
-            and feats.data_ptr() % 16 == 0 and nbr.is_contiguous() and os.environ.get("PBN_WGRAD_DENSE", "0") != "1":
-        f = feats if feats.shape[1] == cin else feats[:, :cin]
-        g = grad_out if grad_out.shape[1] == cout else grad_out[:, :cout]
-        if g.stride(1) != 1 or (g.stride(0) * es) % 16 or g.data_ptr() % 16:
-            g = g.contiguous()
-        return _wgrad_compact(f, g, nbr, cin, cout)
-    dw = torch.empty(k, cin, cout, dtype=torch.float32, device=feats.device)
-    f = feats[:, :cin]
-    g = grad_out[:, :cout].contiguous()
-    kc = max(1, min(k, WGRAD_CHUNK_BYTES // max(1, v * cin * f.element_size())))
-    es = f.element_size()
-    native = f.stride(1) == 1 and (cin * es) % 4 == 0 and (f.stride(0) * es) % 4 == 0 and nbr.is_contiguous()
-    for k0 in range(0, k, kc):
-        kk = min(kc, k - k0)
-        if native:     # one launch: rows gathered through the rulebook columns, zeros where there is no neighbour
-            a = torch.empty(v, kk * cin, dtype=f.dtype, device=f.device)
-            N.check(N.lib().pbn_gather_rulebook_rows(N.c_vp(f.data_ptr()), f.stride(0) * es, cin * es, N.ptr(nbr), k, k0, kk,
-                                                     v, N.c_vp(a.data_ptr()), N.current_stream()),
-                    "pbn_gather_rulebook_rows")
-        else:
-            idx = nbr[:, k0:k0 + kk].long()                                    # [V, kc]
-            a = (f[idx.clamp(min=0)] * (idx >= 0).unsqueeze(-1).to(f.dtype)).reshape(v, -1)
-        dw[k0:k0 + kk] = (a.t() @ g).float().view(-1, cin, cout)
-    return dw
+    return wgrad_native(feats, grad_out, nbr, cin, cout)
 
 
 class _ConvFn(torch.autograd.Function):
@@ -368,8 +335,8 @@ class _LinearFn(torch.autograd.Function):
             packed = pack_weight(weight.detach().unsqueeze(0), grad_out.dtype)      # [1, out, in]: grad_x = grad_out @ W
             gi = spconv_forward(grad_out, None, feats.shape[0], packed)
             grad_feats = gi if gi.shape[1] == feats.shape[1] else gi[:, :feats.shape[1]]
-        if ctx.needs_input_grad[1]:
-            grad_weight = (grad_out.t() @ feats).to(weight.dtype)
+        if ctx.needs_input_grad[1]:                      # dW[out, in] = (x^T g)^T on the same pair-contraction kernel
+            grad_weight = wgrad_native(feats, grad_out, None, feats.shape[1], grad_out.shape[1])[0].t().to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = grad_out.float().sum(0).to(weight.dtype)
         return grad_feats, grad_weight, grad_bias, None

@@ -1,0 +1,115 @@
+// spconv_common.h -- types and per-lane helpers shared by the two convolution kernel families (spconv.hip: LDS weight
+// ring, workgroup tiles; spconv_wave.hip: wave-autonomous tiles, K split over the waves of a workgroup).
+#pragma once
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include "pbn_common.h"
+
+namespace pbn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvArgs {
+    const void* in;      // feature slab [*, ld_in] elements of T (already offset to the first input column)
+    const int* nbr;      // [n_out, K] input rows, -1 = none; nullptr => identity (K must be 1)
+    const int* row_perm; // optional processing order: tile position p handles output row row_perm[p]
+    const int* n_out_dev;
+    const void* w;       // packed weights [n_steps][ntiles_total][64][16 B]
+    const float* scale;  // [cout_p] or nullptr
+    const float* shift;  // [cout_p] or nullptr (bias / folded BN shift)
+    const void* residual;
+    void* out;
+    int ld_in, ld_res, ld_out;
+    unsigned in_bytes, w_bytes;   // extents of the two buffer resources (< 2 GiB, checked by pbn_spconv_forward)
+    int K, vpo, n_steps, ntiles_total;
+    int n_out, relu;
+    int ksplit;          // >1: this launch writes fp32 partial sums, k_spconv_reduce applies the epilogue
+    float* partial;      // [ksplit][n_out_pad][ntiles_total*16]
+    int n_out_pad;
+    int cg;              // steps per barrier group (1..4)
+    int dbg;             // ablation switches for scripts/probe_conv_ablate.py (PBN_CONV_DBG); 0 in production
+};
+
+namespace {
+
+template <typename T> struct Tr;
+template <> struct Tr<float> { static constexpr int ELEMS = 4; };
+template <> struct Tr<__hip_bfloat16> { static constexpr int ELEMS = 8; };
+template <> struct Tr<__half> { static constexpr int ELEMS = 8; };
+
+template <typename T>
+__device__ __forceinline__ void mfma_step(const u32x4& w, const u32x4& x, f32x4& acc);
+
+template <>
+__device__ __forceinline__ void mfma_step<float>(const u32x4& w, const u32x4& x, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[0]), __uint_as_float(x[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[1]), __uint_as_float(x[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[2]), __uint_as_float(x[2]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[3]), __uint_as_float(x[3]), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mfma_step<__hip_bfloat16>(const u32x4& w, const u32x4& x, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mfma_step<__half>(const u32x4& w, const u32x4& x, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+}
+
+// 4 consecutive channels: load as float4 / store from float4
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return f32x4{v.x, v.y, v.z, v.w};
+}
+template <> __device__ __forceinline__ f32x4 load4<__hip_bfloat16>(const __hip_bfloat16* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                 __uint_as_float(v.y & 0xffff0000u)};
+}
+template <> __device__ __forceinline__ f32x4 load4<__half>(const __half* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    const __half2 a = __builtin_bit_cast(__half2, v.x), b = __builtin_bit_cast(__half2, v.y);
+    const float2 fa = __half22float2(a), fb = __half22float2(b);
+    return f32x4{fa.x, fa.y, fb.x, fb.y};
+}
+__device__ __forceinline__ unsigned bf16_rne(float f) {  // round-to-nearest-even, NaN preserved
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const f32x4& v);
+template <> __device__ __forceinline__ void store4<float>(float* p, const f32x4& v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<__hip_bfloat16>(__hip_bfloat16* p, const f32x4& v) {
+    uint2 o;
+    o.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
+    o.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = o;
+}
+template <> __device__ __forceinline__ void store4<__half>(__half* p, const f32x4& v) {
+    const __half2 a = __floats2half2_rn(v[0], v[1]), b = __floats2half2_rn(v[2], v[3]);
+    uint2 o;
+    o.x = __builtin_bit_cast(unsigned, a);
+    o.y = __builtin_bit_cast(unsigned, b);
+    *reinterpret_cast<uint2*>(p) = o;
+}
+
+__device__ __forceinline__ int xcd_tile(int b, int nt) {  // contiguous tile range per XCD (bijective for any nt)
+    const int q = nt >> 3, r = nt & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+}  // namespace
+
+// spconv_wave.hip: wave-autonomous kernel family.  Returns PBN_ERR_UNSUPPORTED when no instantiation fits.
+int launch_wave(const ConvArgs& a, int dtype, int force_cfg, hipStream_t stream);
+// spconv_wave.hip: which levels take the wave-autonomous family (rows of the output level, shapes)
+bool wave_family_wanted(const ConvArgs& a, int dtype);
+
+}  // namespace pbn

@@ -1,0 +1,174 @@
+// wgrad.hip -- weight gradient of the sparse convolution (training, BASELINE configs[2]) on the matrix cores:
+//     dW[k, ci, co] = sum over the rule pairs (i, o) of offset k of  x[i, ci] * g[o, co]
+// (MinkowskiEngine's convolution backward w.r.t. the kernel, reached from /root/reference/train.py:57 `loss.backward()`
+// through network/Mink.py:293-350).  Replaces the gather + library GEMM of round 1 (no rocBLAS in the step any more).
+//
+// Mapping: the contraction runs over PAIRS, so both MFMA operands are read straight from the row-major slabs with no
+// transpose: v_mfma_f32_16x16x4_f32 takes A[i][k] = x[pair k][ci0 + i] and B[k][j] = g[pair k][co0 + j] -- for a fixed
+// pair the 16 lanes of a lane group read 16 CONSECUTIVE channels of one row (one 32/64-byte segment).  bf16 / f16 slabs
+// are widened on load (exact), products are exact in fp32, accumulation is fp32 in pair order: the result does not
+// depend on the slab precision beyond the operands' own rounding.
+//   * workgroup = 4 waves; a wave owns one 16-channel input tile x NTW 16-channel output tiles of ONE offset and a
+//     contiguous quarter of the workgroup's pair range; the four partial tiles are summed through LDS in wave order;
+//   * grid = (tile strips, offsets, pair splits); split partials go to a workspace and are summed in split order by
+//     k_wgrad_reduce: fixed summation order everywhere -> bit-identical run to run (no atomics).
+// Rate: the f32-input MFMA runs at 1/16 of the bf16 rate (MI355X_MICROARCH.md); the bf16 form needs both operands
+// transposed through LDS (ds_read_b64_tr_b16) and is the next step for this kernel.
+#include "pbn_common.h"
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+namespace pbn {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int NTW = 4;   // output-channel tiles per wave
+
+template <typename T> __device__ __forceinline__ float widen(const T* p);
+template <> __device__ __forceinline__ float widen<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float widen<__hip_bfloat16>(const __hip_bfloat16* p) {
+    return __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(p) << 16);
+}
+template <> __device__ __forceinline__ float widen<__half>(const __half* p) { return __half2float(*p); }
+
+struct WgradArgs {
+    const void* x; const void* g;
+    const long long* in_idx; const long long* out_idx;   // pair lists (nullptr: identity, pair p = row p)
+    const int* seg_begin;                                 // [K+1] first segment of every offset (nullptr: one offset, n_pairs pairs)
+    float* out;                                           // dW [K, cin, cout] (splits == 1) or partial [splits, K, cin, cout]
+    int ld_x, ld_g, cin, cout, K, segment, n_pairs, splits, co_groups;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
+    __shared__ float s_red[3][NTW][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kb = lane >> 4;
+    const int k = blockIdx.y;
+    const int ci0 = (blockIdx.x / a.co_groups) * 16, co0 = (blockIdx.x % a.co_groups) * (NTW * 16);
+    // pair range of this offset, of this workgroup's split, of this wave
+    long long p_lo, p_hi;
+    if (a.seg_begin) { p_lo = (long long)a.seg_begin[k] * a.segment; p_hi = (long long)a.seg_begin[k + 1] * a.segment; }
+    else { p_lo = 0; p_hi = a.n_pairs; }
+    const long long len = p_hi - p_lo;
+    const long long per_split = ((len + a.splits - 1) / a.splits + 15) & ~15LL;
+    const long long s_lo = min(p_lo + per_split * blockIdx.z, p_hi), s_hi = min(s_lo + per_split, p_hi);
+    const long long per_wave = (((s_hi - s_lo) + 3) / 4 + 3) & ~3LL;
+    const long long w_lo = min(s_lo + per_wave * wave, s_hi), w_hi = min(w_lo + per_wave, s_hi);
+
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* g = reinterpret_cast<const T*>(a.g);
+    const bool ci_ok = ci0 + j < a.cin;
+    bool co_ok[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) co_ok[t] = co0 + t * 16 + j < a.cout;
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (long long p0 = w_lo; p0 < w_hi; p0 += 8) {       // two MFMA steps (2 x 4 pairs) per trip: independent loads
+        float av[2], bv[2][NTW];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long p = p0 + h * 4 + kb;
+            long long ri = -1, ro = -1;
+            if (p < w_hi) {
+                if (a.in_idx) { ri = a.in_idx[p]; ro = a.out_idx[p]; }
+                else { ri = p; ro = p; }
+            }
+            const bool ok = ri >= 0;
+            av[h] = (ok && ci_ok) ? widen<T>(x + (size_t)ri * a.ld_x + ci0 + j) : 0.f;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+                bv[h][t] = (ok && co_ok[t]) ? widen<T>(g + (size_t)ro * a.ld_g + co0 + t * 16 + j) : 0.f;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h], bv[h][t], acc[t], 0, 0, 0);
+    }
+    // waves 1..3 -> LDS, wave 0 adds them in wave order and stores.  D layout: column = lane & 15 (co), row = kb * 4 + r (ci)
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[wave - 1][t][r * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float* out = a.out + ((size_t)blockIdx.z * a.K + k) * (size_t)a.cin * a.cout;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[t][r];
+            v += s_red[0][t][r * 64 + lane];
+            v += s_red[1][t][r * 64 + lane];
+            v += s_red[2][t][r * 64 + lane];
+            const int ci = ci0 + kb * 4 + r, co = co0 + t * 16 + j;
+            if (ci < a.cin && co < a.cout) out[(size_t)ci * a.cout + co] = v;
+        }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int splits, long long n,
+                                                     float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += partial[(size_t)s * n + i];
+    out[i] = v;
+}
+
+}  // namespace
+}  // namespace pbn
+
+using namespace pbn;
+
+extern "C" size_t pbn_spconv_wgrad_workspace_bytes(int n_offsets, int cin, int cout) {
+    if (n_offsets < 1 || cin < 1 || cout < 1) return 0;
+    return (size_t)64 * n_offsets * cin * cout * sizeof(float);   // up to 64 pair splits
+}
+
+extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g, int dtype, const int64_t* in_idx,
+                                const int64_t* out_idx, const int32_t* seg_begin, int segment, int n_pairs_total,
+                                int n_offsets, int cin, int cout, float* dw, void* workspace, size_t workspace_bytes,
+                                pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_offsets < 1 || cin < 1 || cout < 1 || n_pairs_total < 0 || !dw) return PBN_ERR_ARG;
+    if ((in_idx == nullptr) != (out_idx == nullptr)) return PBN_ERR_ARG;
+    if (seg_begin && (segment < 1 || !in_idx)) return PBN_ERR_ARG;
+    if (!seg_begin && n_offsets != 1) return PBN_ERR_ARG;
+    const long long n_out = (long long)n_offsets * cin * cout;
+    if (n_pairs_total == 0) {
+        PBN_HIP_CHECK(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)n_out, stream));
+        return PBN_OK;
+    }
+    if (!x || !g) return PBN_ERR_ARG;
+    WgradArgs a;
+    a.x = x; a.g = g; a.in_idx = (const long long*)in_idx; a.out_idx = (const long long*)out_idx; a.seg_begin = seg_begin;
+    a.ld_x = ld_x; a.ld_g = ld_g; a.cin = cin; a.cout = cout; a.K = n_offsets; a.segment = segment; a.n_pairs = n_pairs_total;
+    a.co_groups = cdiv(cout, NTW * 16);
+    const int strips = cdiv(cin, 16) * a.co_groups;
+    // pair splits: enough workgroups for the chip (~2048), at least ~512 pairs per workgroup, bounded by the workspace
+    const long long pairs_per_offset = n_pairs_total / n_offsets + 1;
+    long long splits = 2048 / ((long long)strips * n_offsets) + 1;
+    if (splits > pairs_per_offset / 512 + 1) splits = pairs_per_offset / 512 + 1;
+    const long long by_ws = workspace ? (long long)(workspace_bytes / (sizeof(float) * (size_t)n_out)) : 1;
+    if (splits > by_ws) splits = by_ws;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+    a.splits = (int)splits;
+    a.out = splits > 1 ? (float*)workspace : dw;
+    const dim3 grid(strips, n_offsets, (unsigned)splits);
+    switch (dtype) {
+        case PBN_F32: hipLaunchKernelGGL(k_wgrad<float>, grid, dim3(256), 0, stream, a); break;
+        case PBN_BF16: hipLaunchKernelGGL(k_wgrad<__hip_bfloat16>, grid, dim3(256), 0, stream, a); break;
+        case PBN_F16: hipLaunchKernelGGL(k_wgrad<__half>, grid, dim3(256), 0, stream, a); break;
+        default: return PBN_ERR_ARG;
+    }
+    if (splits > 1)
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n_out, 256)), dim3(256), 0, stream, (const float*)workspace, (int)splits,
+                           n_out, dw);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}

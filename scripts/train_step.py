@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Training step of BASELINE configs[2]: batch = N ScanNet-sized scenes, one per rank, model_fn forward + losses +
+backward, gradient all-reduce over RCCL overlapped with backward (pbnet_amd.dist.GradientReducer; train.py:345), Adam.
+
+    python scripts/train_step.py                       # one rank, process group still initialised through `nccl`
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
+        scripts/train_step.py --steps 10               # configs[2] on one 8-GPU node
+
+Every rank draws its own synthetic scene (seeds 10 + rank), teacher-forced heads so that the cluster
+stage is active from the first step.  Rank 0 prints one JSON line: scenes/s over all ranks (max-over-ranks time), the
+all-reduce share, the loss of the last step."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--comm-dtype", default="f32", choices=["bf16", "f32"], help="gradient dtype on the wire")
+    ap.add_argument("--no-overlap", action="store_true", help="all-reduce after backward instead of from gradient hooks")
+    ap.add_argument("--small", action="store_true", help="a 20 k-point room instead of a ScanNet-sized scene (smoke runs)")
+    args = ap.parse_args()
+    import torch.distributed as dist
+    from pbnet_amd import dist as pd, synth
+    from pbnet_amd.config import get_config
+    from pbnet_amd.network.PBNet import PBNet, model_fn
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
+    cfg = get_config(batch_size=1, cluster_epoch=0)
+    torch.manual_seed(22)                                           # same initial weights on every rank
+    model = PBNet(cfg).to(dev).train()
+    kw = dict(room=(1.6, 1.3, 1.2), n_boxes=4, pitch=0.03, classes=(17, 10)) if args.small else {}
+    batch_np, teacher_np, info = synth.make_train_batch(seed=10 + rank, copies=1, **kw)
+    t = torch.from_numpy
+    batch = {k: t(v).to(dev) for k, v in batch_np.items()}
+    batch["feat_voxel"] = batch["feat_voxel"].to(dtype)
+    teacher = {k: t(v).to(dev) for k, v in teacher_np.items()}
+    fwd = model.forward
+    model.forward = lambda *a, **k: fwd(*a, teacher=teacher, **k)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    reducer = pd.GradientReducer(model.parameters(), comm_dtype={"bf16": torch.bfloat16, "f32": torch.float32}[args.comm_dtype],
+                                 overlap=not args.no_overlap)
+    t_comm = [0.0]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, pred, visual, meter = model_fn(batch, model, 1, cfg, "train")
+        loss.backward()
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        reducer.finish()                                            # waits for the buckets issued during backward
+        torch.cuda.synchronize()
+        t_comm[0] += time.perf_counter() - c0
+        opt.step()
+        return loss
+    for _ in range(args.warmup):
+        step()
+    t_comm[0] = 0.0
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    pd.sync_buffers(model)                                          # what precedes validation / checkpoint_save
+    lossv = torch.tensor([float(loss)], device=dev)
+    dist.all_reduce(lossv)
+    if rank == 0:
+        e = float(el.item())
+        print(json.dumps({"metric": "training scenes/s (configs[2]: bf16 step, one scene per rank, RCCL gradient all-reduce)",
+                          "value": round(world * args.steps / e, 3), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+                          "ms_per_step": round(e / args.steps * 1e3, 2), "dtype": args.dtype, "comm_dtype": args.comm_dtype,
+                          "allreduce_tail_ms_per_step": round(t_comm[0] / args.steps * 1e3, 2), "overlap": not args.no_overlap,
+                          "mean_loss_last_step": round(float(lossv) / world, 5),
+                          "points_per_scene": info["n_points"], "voxels_per_scene": info["n_voxels"]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -381,3 +381,52 @@ def test_unet_forward_is_graph_capturable_fp16(golden_dir):
             assert torch.equal(out, eager)
     want = torch.from_numpy(g["out_eval"])
     assert ((out.float().cpu() - want).norm() / want.norm()).item() < 5e-3
+
+
+WAVE_CFGS = (401, 402, 404, 406, 408, 204, 206, 208, 1401, 1402, 1404, 1201, 1202, 1204)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL), (torch.bfloat16, 6e-2), (torch.float16, 1e-2)])
+@pytest.mark.parametrize("cin,cout,k", [(32, 96, 3), (64, 128, 3), (6, 32, 5), (40, 64, 5), (96, 128, 1), (16, 16, 1)])
+def test_wave_family_configurations(dtype, tol, cin, cout, k):
+    """Every built configuration of the wave-autonomous family (csrc/spconv_wave.hip: row-split and K-split modes, 16-row
+    fragment counts, channel-tile counts) against the oracle on the same convolution, with the full fused epilogue
+    (scale, shift, residual, ReLU); run-to-run bit-identical; all configurations agree with each other to fp32
+    re-association."""
+    from pbnet_amd.MinkowskiEngine.conv import spconv_forward, _pad_vec
+    from pbnet_amd import _native as N
+    coords = _scene_coords(47, room=(1.0, 0.8, 0.6), batch=1)
+    n = len(coords)
+    torch.manual_seed(cin * 100 + cout + k)
+    feats = torch.randn(n, cin)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=k, dimension=3)
+    cm_ref = R.CoordinateManager(coords)
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout) * 0.1
+    res = torch.randn(n, cout)
+    q = (lambda t: t.to(dtype).float())
+    want = R.conv(q(feats), q(conv.kernel.detach()), None if k == 1 else cm_ref.get_map(1, 1, k), n)
+    want = torch.relu(want * scale + shift + q(res))
+    conv = conv.to(DEV)
+    x = ME.SparseTensor(feats.to(dtype), torch.from_numpy(coords), device=DEV)
+    packed = conv._cache.get(conv.kernel, dtype)
+    cout_p = packed[3]
+    nbr = None if k == 1 else x.coordinate_manager.kernel_map(1, k)
+    sc, sh = _pad_vec(scale.to(DEV), cout_p, 1.0), _pad_vec(shift.to(DEV), cout_p, 0.0)
+    resd = torch.zeros(n, cout_p, dtype=dtype, device=DEV)
+    resd[:, :cout] = res.to(dtype).to(DEV)
+    ran = 0
+    for cfg in WAVE_CFGS:
+        nt = cfg % 100
+        if (cout_p // 16) % nt:
+            continue
+        try:
+            o1 = spconv_forward(x.F, nbr, n, packed, scale=sc, shift=sh, residual=resd, relu=True, rows_per_wave=cfg)
+        except RuntimeError as e:                 # e.g. K = 125 with a 256-row tile: more LDS than a CU has
+            assert "UNSUPPORTED" in str(e), e
+            continue
+        o2 = spconv_forward(x.F, nbr, n, packed, scale=sc, shift=sh, residual=resd, relu=True, rows_per_wave=cfg)
+        assert torch.equal(o1, o2), "cfg %d not deterministic" % cfg
+        _close(o1[:, :cout].float().cpu(), want, "wave cfg %d %d->%d k=%d %s" % (cfg, cin, cout, k, dtype),
+               tol if dtype == torch.float32 else tol * max(1.0, want.abs().max().item()))
+        ran += 1
+    assert ran >= 4
