@@ -26,6 +26,14 @@ namespace {
 constexpr unsigned OOB = 0x80000000u;   // >= num_records of either resource: the load returns zeros
 constexpr unsigned UNIT_NONE = 0xffff0000u;   // step 0 (any valid weight address), offset 255 (no such offset): adds zeros
 
+constexpr int MAX_DEPTH = 8;
+// units in flight per wave.  Measured on the bench scene (scripts/probe_wave.py): 2 beats the deeper pipelines on every
+// level -- occupancy (registers) and the issue cost of the extra in-flight loads outweigh the latency they would hide
+constexpr int pipe_depth(int nf, int nt) {
+    (void)nf; (void)nt;
+    return 2;
+}
+
 template <int NF, int NT>
 struct Stage {
     u32x4 w[NT];
@@ -65,12 +73,13 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     constexpr int TM = KSPLIT ? RW : KW * RW;            // rows per workgroup
     constexpr int NTB = NT < 2 ? NT : 2;                 // channel tiles per LDS reduction round (K-split)
     constexpr int TPB = KW * 64;
+    constexpr int B = pipe_depth(NF, NT);                // units in flight per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = a.K;
     const int KS = K | 1;
     int* s_nbr = reinterpret_cast<int*>(smem);                                        // TM * KS
     unsigned* s_units = reinterpret_cast<unsigned*>(s_nbr + ((TM * KS + 3) & ~3));    // KW * (n_steps + 2)
-    const int units_pitch = a.n_steps + 2;
+    const int units_pitch = a.n_steps + 2 * MAX_DEPTH;
     float* s_red = reinterpret_cast<float*>(s_units + ((KW * units_pitch + 3) & ~3)); // K-split: KW * TM * NTB*16 floats
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -149,8 +158,8 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
             base += __popcll(m);
         }
         n_units = KSPLIT ? (base > wave ? (base - wave + KW - 1) / KW : 0) : base;
-        // two sentinels so that the loop below can run in pairs without a tail
-        if (lane < 2) my_units[n_units + lane] = UNIT_NONE;
+        // sentinels: the pipeline below always has B units in flight and needs no tail handling
+        if (lane < 2 * B) my_units[n_units + lane] = UNIT_NONE;
     }
     __syncthreads();   // (the list is wave-private; a workgroup barrier is the simplest fence for it)
 
@@ -202,15 +211,20 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     };
 
     {
-        Stage<NF, NT> sa, sb;
-        issue(sa, 0);
-        for (int i = 0; i < n_units; i += 2) {
-            issue(sb, i + 1);
-            compute(sa);
-            issue(sa, i + 2);
-            compute(sb);
+        // B units in flight: a unit's registers are refilled with the unit B positions ahead as soon as its MFMAs are
+        // issued (loads retire in order, so the compiler's counted vmcnt waits are exact); a coarse-level wave-unit is
+        // ~100 cycles of MFMA against ~1500 cycles of L2 latency, hence the depth
+        Stage<NF, NT> st[B];
+#pragma unroll
+        for (int s = 0; s < B; ++s) issue(st[s], s);
+        for (int i = 0; i < n_units; i += B) {
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+                compute(st[s]);
+                issue(st[s], i + B + s);
+            }
         }
-        // the last issue(sa, ...) read a sentinel: its loads are harmless and never consumed
+        // the trailing issues read sentinels: harmless loads that are never consumed
     }
 
     if constexpr (!KSPLIT) {
@@ -261,7 +275,8 @@ int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     constexpr int NTB = NT < 2 ? NT : 2;
     if (a.ntiles_total % NT) return PBN_ERR_UNSUPPORTED;
     const int KS = a.K | 1;
-    size_t lds = sizeof(int) * (size_t)((TM * KS + 3) & ~3) + sizeof(unsigned) * (size_t)((KW * (a.n_steps + 2) + 3) & ~3);
+    size_t lds = sizeof(int) * (size_t)((TM * KS + 3) & ~3) +
+                 sizeof(unsigned) * (size_t)((KW * (a.n_steps + 2 * MAX_DEPTH) + 3) & ~3);
     if (KSPLIT) lds += sizeof(float) * (size_t)KW * TM * NTB * 16;
     if (lds > 160 * 1024 || a.K > 128 || a.n_steps > 0xfffe) return PBN_ERR_UNSUPPORTED;
     auto kern = k_spconv_wave<T, NF, NT, KW, KSPLIT>;
@@ -300,30 +315,26 @@ int launch_by_cfg(const ConvArgs& a, int cfg, hipStream_t stream) {
 int pick_cfg(const ConvArgs& a) {
     const int ntt = a.ntiles_total;
     const long long rows = a.n_out;
-    auto nt_le = [&](int cap) { for (int c : {8, 6, 4, 2, 1}) if (c <= cap && ntt % c == 0) return c; return 1; };
-    static const int ksplit_rows = getenv("PBN_WAVE_KSPLIT_ROWS") ? atoi(getenv("PBN_WAVE_KSPLIT_ROWS")) : 20000;
-    if (rows < ksplit_rows) {
-        // K-split: TM = 64 (NF 4) or 32 (NF 2); channel tiles per workgroup 4 / 2 / 1 -- widest split that still yields
-        // ~256 workgroups, never narrower than needed
-        for (int nf : {4, 2})
-            for (int nt : {4, 2, 1}) {
-                if (ntt % nt) continue;
-                const long long wgs = ((rows + nf * 16 - 1) / (nf * 16)) * (ntt / nt);
-                if (wgs >= 224) return 1000 + nf * 100 + nt;
-            }
-        return 1000 + 200 + (ntt % 2 == 0 && ntt > 2 ? 2 : 1);
+    // K-split candidates from the widest tile down; the first one that gives the chip one round of workgroups wins
+    // (fitted on scripts/probe_wave.py: 1202 on the 791-row level, 1204 / 1404 on the 3.5 k- and 14.7 k-row levels)
+    int best = 0;
+    long long best_wgs = -1;
+    for (int cfg : {1404, 1204, 1402, 1202, 1401, 1201}) {
+        const int nf = (cfg / 100) % 10, nt = cfg % 100;
+        if (ntt % nt) continue;
+        const long long wgs = ((rows + nf * 16 - 1) / (nf * 16)) * (ntt / nt);
+        if (wgs >= 180) return cfg;
+        if (wgs > best_wgs) { best_wgs = wgs; best = cfg; }
     }
-    const int nt = nt_le(8);
-    if (nt == 8 || nt == 6 || nt == 4) return 400 + nt;
-    return 400 + nt;
+    return best ? best : 1201;
 }
 
 template <typename T>
 int launch_t(const ConvArgs& a, int force_cfg, hipStream_t stream) {
     int cfg = force_cfg > 0 ? force_cfg : pick_cfg(a);
     int rc = launch_by_cfg<T>(a, cfg, stream);
-    if (rc == PBN_ERR_UNSUPPORTED && force_cfg <= 0) {   // e.g. K = 125 with a large tile: fall back to smaller tiles
-        for (int alt : {204, 1202, 1201}) {
+    if (rc == PBN_ERR_UNSUPPORTED && force_cfg <= 0) {   // e.g. K = 125: the rulebook tile + reduction buffer exceed LDS
+        for (int alt : {1202, 1201, 204}) {
             rc = launch_by_cfg<T>(a, alt, stream);
             if (rc != PBN_ERR_UNSUPPORTED) break;
         }
@@ -342,15 +353,21 @@ int launch_wave(const ConvArgs& a, int dtype, int force_cfg, hipStream_t stream)
     }
 }
 
-// PBN_CONV_FAMILY: 0 = LDS-ring kernels only (round 1), 1 = wave kernels only, 2 (default) = by level size
+// PBN_CONV_FAMILY: 0 = workgroup-tile kernels only (round 1), 1 = wave kernels only, 2 (default) = by size of the op.
+// Measured crossover (scripts/probe_wave.py, HIP-graph replay): the K-split wave kernel is level with or ahead of the
+// workgroup-tile kernel + its split-K reduce launch up to ~6e9 dense MACs (rows x K x C_in x C_out) on levels below 20 k
+// rows, and behind it above (L3 384->256, L2 128->128) and on every wide level.
 bool wave_family_wanted(const ConvArgs& a, int dtype) {
     (void)dtype;
     static const int fam = getenv("PBN_CONV_FAMILY") ? atoi(getenv("PBN_CONV_FAMILY")) : 2;
     static const int max_rows = getenv("PBN_WAVE_MAX_ROWS") ? atoi(getenv("PBN_WAVE_MAX_ROWS")) : 20000;
+    static const double max_macs = getenv("PBN_WAVE_MAX_GMACS") ? atof(getenv("PBN_WAVE_MAX_GMACS")) * 1e9 : 6.3e9;
     if (a.K > 128) return false;
     if (fam == 0) return false;
     if (fam == 1) return true;
-    return a.n_out < max_rows;
+    const double elems_per_step = 4.0 * (dtype == PBN_F32 ? 4.0 : 8.0);
+    const double dense = (double)a.n_out * a.n_steps * elems_per_step * a.ntiles_total * 16.0;
+    return a.n_out < max_rows && dense <= max_macs;
 }
 
 }  // namespace pbn

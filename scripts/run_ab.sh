@@ -7,7 +7,8 @@ O=gpurun_out/${1:-ab}
 mkdir -p $O
 python -m pytest tests/test_backbone_gpu.py -m gpu -q -x -s > $O/test_backbone.log 2>&1; echo "backbone tests rc=$?"; tail -2 $O/test_backbone.log
 PBN_CONV_FAMILY=1 python -m pytest tests/test_backbone_gpu.py tests/test_pbnet_gpu.py tests/test_bench_workload_gpu.py -m gpu -q -x > $O/test_family1.log 2>&1; echo "family1 tests rc=$?"; tail -2 $O/test_family1.log
-for fam in 0 2 1; do
+python -m pytest tests/test_train_gpu.py -m gpu -q -x -s > $O/test_train.log 2>&1; echo "train tests rc=$?"; tail -2 $O/test_train.log
+for fam in ${FAMS:-0 2 1}; do
   PBN_CONV_FAMILY=$fam python scripts/probe_ops.py > $O/probe_ops_fam$fam.log 2>&1
   grep "total" $O/probe_ops_fam$fam.log | tr '\n' ' '; echo " <- family $fam"
   PBN_CONV_FAMILY=$fam python bench.py --no-extras --steps 40 --repeats 3 > $O/bench_fam$fam.json 2>$O/bench_fam$fam.err

