@@ -67,7 +67,9 @@ size_t pbn_cluster_workspace_bytes(int n_points, int n_segments, int general_sem
 
 int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, const int32_t* sem, const int32_t* seg_len,
                        int n_points, int n_segments, float radius, int min_pts, float para_f, int nv_flag,
-                       int general_sem, int32_t* cluster_id, int32_t* cluster_num, int32_t* den, float* centers,
+                       int general_sem /* bit 0: general (mixed-class) rule; bit 1: n_points is a CAPACITY -- the points that
+                       exist are the first sum(seg_len) rows, a count that stays on the device (capacity-planned forward:
+                       no host read-back between class selection and grouping) */, int32_t* cluster_id, int32_t* cluster_num, int32_t* den, float* centers,
                        int32_t* clt_sem, int32_t* n_clusters, int32_t* member_start, int32_t* member_idx,
                        void* workspace, size_t workspace_bytes, pbn_stream_t stream);
 
@@ -257,6 +259,60 @@ int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g, int dtype
                      const int64_t* out_idx, const int32_t* seg_begin, int segment, int n_pairs_total, int n_offsets,
                      int cin, int cout, float* dw, void* workspace, size_t workspace_bytes, pbn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Capacity-planned inference (csrc/plan.hip): the data-dependent sizes of PBNet.forward stay on the device.  Every buffer
+ * is allocated at a CAPACITY chosen by the caller (pbnet_amd/planned.py takes them from a previous forward of a scene of the
+ * same size class); kernels read the true counts from `counts` (int32[PBN_CNT_WORDS]) and raise bits of
+ * counts[PBN_CNT_OVERFLOW] instead of writing past a capacity (the caller then falls back to the size-exact path).
+ * The `_dev` variants of the stage kernels take (capacity, pointer to the device-side count).
+ *   pbn_class_gate       network/PBNet.py:151-160,172-173: classes with (float)count < thr05[c] are dropped; class_base[c]
+ *                        = first output slot of class c (-1 dropped), seg_len[(c-2)*nb + b] = points of (class, batch)
+ *                        (0 for dropped classes: the grouping skips empty segments), counts[PBN_CNT_POINTS].
+ *   pbn_local_plan       network/PBNet.py:182-234 for task 'test': one local scene per cluster; entry table in the layout
+ *                        pbn_local_scene_rows reads; counts[ENTRIES, ROWS, SCENES, CLUSTERS].  kNN of the cluster centres:
+ *                        ascending (d^2, id) with d^2 = (dx^2+dy^2)+dz^2 in unfused fp32.
+ *   pbn_proposal_offsets network/PBNet.py:330-345: proposals_offset i64[s_cap+1], surviving scene ids, dense renumbering;
+ *                        counts[PROPOSALS, PROPOSAL_ROWS].
+ *   pbn_batch_starts     seg_start[s] = first row of a batch-sorted [n,4] coordinate list whose batch index is >= s. */
+enum {
+    PBN_CNT_POINTS = 0, PBN_CNT_CLUSTERS = 1, PBN_CNT_ENTRIES = 2, PBN_CNT_ROWS = 3, PBN_CNT_SCENES = 4,
+    PBN_CNT_PROPOSAL_ROWS = 5, PBN_CNT_PROPOSALS = 6, PBN_CNT_OVERFLOW = 7, PBN_CNT_WORDS = 16
+};
+enum {
+    PBN_OVF_POINTS = 1, PBN_OVF_CLUSTERS = 2, PBN_OVF_ENTRIES = 4, PBN_OVF_ROWS = 8, PBN_OVF_SEGMENT = 16,
+    PBN_OVF_BATCH = 32, PBN_OVF_LEVEL = 64
+};
+int pbn_class_gate(const int32_t* table, const float* thr05, int n_classes, int nb, int m_cap, int n_points,
+                   int32_t* class_base, int32_t* seg_len, int32_t* counts, pbn_stream_t stream);
+size_t pbn_local_plan_workspace_bytes(int c_cap);
+int pbn_local_plan(const int32_t* cluster_num, int n_segments, int nb, const int32_t* member_start, const float* centers,
+                   const int32_t* n_clusters, const float* thr02, const int32_t* kmax, int c_cap, int e_cap, int r_cap,
+                   int32_t* ent_row_start, int32_t* ent_member_start, int32_t* ent_scene, float* ent_weight,
+                   int32_t* counts, void* workspace, size_t workspace_bytes, pbn_stream_t stream);
+int pbn_proposal_offsets(const int32_t* per_scene, int s_cap, int64_t* proposals_offset, int64_t* alive_ids,
+                         int32_t* dense_of, int32_t* counts, pbn_stream_t stream);
+int pbn_batch_starts(const int32_t* coords, const int32_t* n_dev, int n_cap, int n_segments, int32_t* seg_start,
+                     pbn_stream_t stream);
+int pbn_local_scene_rows_dev(const int32_t* ent_row_start, const int32_t* ent_member_start, const int32_t* ent_scene,
+                             const float* ent_weight, int n_ent_cap, int n_rows_cap, const int32_t* n_ent_dev,
+                             const int32_t* n_rows_dev, const int32_t* member_idx, const int64_t* ins_ind, const float* xyz,
+                             float inv_voxel, const void* point_feat, int ld_feat, int channels, const void* sem_score,
+                             int ld_sem, const int64_t* sem_pred, int dtype, int64_t* point_idx, int64_t* row_scene,
+                             int32_t* coords, void* feat_out, int ld_out, pbn_stream_t stream);
+int pbn_gather_pad_rows_dev(const void* in, int ld_in_bytes, int row_bytes, const int64_t* idx, const int64_t* idx2,
+                            int n_cap, const int32_t* n_dev, void* out, int ld_out_bytes, pbn_stream_t stream);
+int pbn_mlp_rows_dev(const void* in, int ld_in, int channels, const int64_t* idx_a, const int64_t* idx_b, int n_cap,
+                     const int32_t* n_dev, const float* w1, const float* scale, const float* shift, const float* slope,
+                     int hidden, const float* w2, const float* b2, int n_out, int sigmoid, void* out, int ld_out, int dtype,
+                     pbn_stream_t stream);
+int pbn_mask_count_dev(const void* mask_score, int ld, float thd, const int64_t* row_scene, int n_cap, const int32_t* n_dev,
+                       int n_scenes_cap, int dtype, int32_t* per_scene, int32_t* block_cnt, pbn_stream_t stream);
+int pbn_proposal_rows_dev(const void* mask_score, int ld, float thd, const int64_t* row_scene, const int64_t* point_idx,
+                          int n_cap, const int32_t* n_dev, const int32_t* dense_of, const int32_t* block_cnt,
+                          const float* xyz, float scale, float inv_voxel, const void* point_feat, int ld_feat, int channels,
+                          int dtype, int64_t* proposals_idx, void* proposals_ms, int32_t* coords, void* feat_out,
+                          pbn_stream_t stream);
+
 /* pbn_mlp_rows -- the two-layer heads of network/PBNet.py:43-82 in eval mode, one launch per head:
  *   out[i, 0:n_out] = act( W2 . prelu( (W1 . x) * scale + shift ) + b2 ),   x = in[row(i), 0:channels],
  *   row(i) = idx_b[idx_a[i]] (either index level may be NULL), act = sigmoid or identity.
@@ -376,6 +432,8 @@ typedef struct {
 } pbn_prepare_layout;
 
 size_t pbn_coords_prepare_bytes(int n, int want_k5, pbn_prepare_layout* layout);
+int pbn_coords_prepare_dev(const int32_t* coords, const int32_t* n_dev, int n_cap, int want_k5, int x_fastest, void* arena,
+                           size_t arena_bytes, const pbn_prepare_layout* layout, pbn_stream_t stream);
 int pbn_coords_prepare(const int32_t* coords, int n, int want_k5, int x_fastest, void* arena, size_t arena_bytes,
                        const pbn_prepare_layout* layout, pbn_stream_t stream);
 
@@ -403,6 +461,10 @@ typedef struct {
 } pbn_unet_buf;
 
 size_t pbn_unet_arena_bytes(const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows, int dtype, int64_t* buf_offsets);
+int pbn_unet_forward_dev(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows_cap,
+                         const int32_t* n_rows_dev, const void* input, int ld_input, const int32_t* const* k3,
+                         const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
+                         size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream);
 int pbn_unet_forward(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows,
                      const void* input, int ld_input, const int32_t* const* k3, const int32_t* k5,
                      const int32_t* const* down, const int32_t* const* up, void* arena, size_t arena_bytes, int dtype,

@@ -112,6 +112,26 @@ SIGNATURES = {
     "pbn_coords_build": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(CoordsLayout), c_vp]),
     "pbn_coords_prepare_bytes": (c_size, [c_int, c_int, ctypes.POINTER(PrepareLayout)]),
     "pbn_coords_prepare": (c_int, [c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(PrepareLayout), c_vp]),
+    "pbn_coords_prepare_dev": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(PrepareLayout), c_vp]),
+    "pbn_unet_forward_dev": (c_int, [ctypes.POINTER(UnetOp), c_int, ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32),
+                                     c_i32p, c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp,
+                                     ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_vp, c_size, c_int,
+                                     c_vp, c_size, c_vp]),
+    "pbn_class_gate": (c_int, [c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_i32p, c_i32p, c_i32p, c_vp]),
+    "pbn_local_plan_workspace_bytes": (c_size, [c_int]),
+    "pbn_local_plan": (c_int, [c_i32p, c_int, c_int, c_i32p, c_f32p, c_i32p, c_f32p, c_i32p, c_int, c_int, c_int, c_i32p,
+                               c_i32p, c_i32p, c_f32p, c_i32p, c_vp, c_size, c_vp]),
+    "pbn_proposal_offsets": (c_int, [c_i32p, c_int, c_vp, c_vp, c_i32p, c_i32p, c_vp]),
+    "pbn_batch_starts": (c_int, [c_i32p, c_i32p, c_int, c_int, c_i32p, c_vp]),
+    "pbn_local_scene_rows_dev": (c_int, [c_i32p, c_i32p, c_i32p, c_f32p, c_int, c_int, c_i32p, c_i32p, c_i32p, c_vp, c_f32p,
+                                         c_float, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i32p, c_vp,
+                                         c_int, c_vp]),
+    "pbn_gather_pad_rows_dev": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i32p, c_vp, c_int, c_vp]),
+    "pbn_mlp_rows_dev": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int,
+                                 c_f32p, c_f32p, c_int, c_int, c_vp, c_int, c_int, c_vp]),
+    "pbn_mask_count_dev": (c_int, [c_vp, c_int, c_float, c_vp, c_int, c_i32p, c_int, c_int, c_i32p, c_i32p, c_vp]),
+    "pbn_proposal_rows_dev": (c_int, [c_vp, c_int, c_float, c_vp, c_vp, c_int, c_i32p, c_i32p, c_i32p, c_f32p, c_float,
+                                      c_float, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_i32p, c_vp, c_vp]),
     "pbn_morton_keys": (c_int, [c_i32p, c_i32p, c_int, c_vp, c_vp]),
     "pbn_unet_arena_bytes": (c_size, [ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32), c_int,
                                       ctypes.POINTER(c_i64)]),

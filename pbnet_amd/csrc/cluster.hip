@@ -63,7 +63,7 @@ __device__ __forceinline__ int hash_lookup(const unsigned long long* __restrict_
 }
 
 // ---- segment offsets: exclusive scan of seg_len by one wave; status != 0 when the lengths do not add up -------
-__global__ void k_seg_offsets(const int* __restrict__ seg_len, int n_seg, int n, int* __restrict__ seg_off,
+__global__ void k_seg_offsets(const int* __restrict__ seg_len, int n_seg, int n, int capacity, int* __restrict__ seg_off,
                               int* __restrict__ status) {
     const int lane = lane_id();
     int carry = 0;
@@ -84,9 +84,17 @@ __global__ void k_seg_offsets(const int* __restrict__ seg_len, int n_seg, int n,
     bad = __any(bad);
     if (lane == 0) {
         seg_off[n_seg] = carry;
-        if (carry != n || bad) atomicOr(status, 1);
+        if ((capacity ? carry > n : carry != n) || bad) atomicOr(status, 1);
     }
 }
+
+// Point count of a launch: `cap` sizes the grids and the workspace; in capacity mode (pbn_binary_cluster flags bit 1) the
+// number of points that exist is the sum of the segment lengths, read from device memory (seg_off[n_seg])
+struct NRef {
+    int cap;
+    const int* dev;
+    __device__ __forceinline__ int get() const { return dev ? min(cap, *dev) : cap; }
+};
 
 __device__ __forceinline__ int find_segment(const int* __restrict__ seg_off, int n_seg, int i) {
     int lo = 0, hi = n_seg;  // largest s with seg_off[s] <= i
@@ -99,10 +107,11 @@ __device__ __forceinline__ int find_segment(const int* __restrict__ seg_off, int
 
 // ---- grid hash build: one slot per occupied (segment, cell); per-slot population ------------------------------
 __global__ __launch_bounds__(TPB) void k_cell_insert(const float* __restrict__ off_xyz, const int* __restrict__ sem,
-                                                    const int* __restrict__ seg_off, int n_seg, int n, float inv_cell,
+                                                    const int* __restrict__ seg_off, int n_seg, NRef n_ref, float inv_cell,
                                                     unsigned long long* __restrict__ hkeys, int* __restrict__ hcount,
                                                     unsigned hmask, int* __restrict__ slot_of_pt,
                                                     int* __restrict__ seg_of_pt, int* __restrict__ status) {
+    const int n = n_ref.get();
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     const int s = sem[i];
@@ -122,11 +131,12 @@ __global__ __launch_bounds__(TPB) void k_cell_insert(const float* __restrict__ o
 }
 
 // ---- scatter points into the cell-sorted slab: float4(x, y, z, bits(original index)) --------------------------
-__global__ __launch_bounds__(TPB) void k_cell_scatter(const float* __restrict__ off_xyz, int n,
+__global__ __launch_bounds__(TPB) void k_cell_scatter(const float* __restrict__ off_xyz, NRef n_ref,
                                                      const int* __restrict__ slot_of_pt, const int* __restrict__ hstart,
                                                      int* __restrict__ hcursor, const int* __restrict__ seg_of_pt,
                                                      float4* __restrict__ spt, int* __restrict__ sseg,
                                                      int* __restrict__ sslot) {
+    const int n = n_ref.get();
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     const int slot = slot_of_pt[i];
@@ -207,10 +217,11 @@ __device__ __forceinline__ int group_max(int v) {
     for (int o = 1; o < NB_Q; o <<= 1) v = max(v, __shfl_xor(v, o, 64));
     return v;
 }
-__global__ __launch_bounds__(TPB) void k_count(const float4* __restrict__ spt, const int* __restrict__ sseg, int n,
+__global__ __launch_bounds__(TPB) void k_count(const float4* __restrict__ spt, const int* __restrict__ sseg, NRef n_ref,
                                               float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
                                               unsigned hmask, const int* __restrict__ hstart,
                                               const int* __restrict__ hcount, int* __restrict__ den) {
+    const int n = n_ref.get();
     const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
     int p = (int)(t / NB_Q);
     const int q = (int)(t % NB_Q);
@@ -236,9 +247,10 @@ __global__ __launch_bounds__(TPB) void k_count(const float4* __restrict__ spt, c
 }
 
 // tag the HP flag into bit 31 of the index word of the sorted slab; init union-find parents
-__global__ __launch_bounds__(TPB) void k_tag_hp(float4* __restrict__ spt, int n, const int* __restrict__ den, int min_pts,
+__global__ __launch_bounds__(TPB) void k_tag_hp(float4* __restrict__ spt, NRef n_ref, const int* __restrict__ den, int min_pts,
                                                int* __restrict__ parent, int* __restrict__ lab,
                                                const int* __restrict__ sslot, int* __restrict__ cell_rep) {
+    const int n = n_ref.get();
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= n) return;
     const int i = __float_as_int(spt[p].w);
@@ -282,11 +294,12 @@ __device__ __forceinline__ int uf_union(int* __restrict__ parent, int a, int b) 
 //  * untrusted (clamped border) cells fall back to pairwise unions, each edge handled by its larger endpoint.
 // Every HP-HP edge (i,j) ends with find(i) == find(j): either both cells are trusted and chained to representatives
 // that some witness joined, or the pairwise fallback handled the edge itself.
-__global__ __launch_bounds__(TPB) void k_union(const float4* __restrict__ spt, const int* __restrict__ sseg, int n,
+__global__ __launch_bounds__(TPB) void k_union(const float4* __restrict__ spt, const int* __restrict__ sseg, NRef n_ref,
                                               float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
                                               unsigned hmask, const int* __restrict__ hstart,
                                               const int* __restrict__ hcount, int* parent,
                                               const int* __restrict__ cell_rep, const int* __restrict__ sslot, int pass) {
+    const int n = n_ref.get();
     // pass 0: every HP chains to its cell representative; only the representatives (and points of untrusted cells)
     //         look across cells -- a few hundred threads do almost all merging without contention;
     // (k_compress flattens the forest in between)
@@ -341,7 +354,8 @@ __global__ __launch_bounds__(TPB) void k_union(const float4* __restrict__ spt, c
 }
 
 // flatten the forest between the two union passes: afterwards parent[i] is i's root for every HP
-__global__ __launch_bounds__(TPB) void k_compress(const float4* __restrict__ spt, int n, int* parent) {
+__global__ __launch_bounds__(TPB) void k_compress(const float4* __restrict__ spt, NRef n_ref, int* parent) {
+    const int n = n_ref.get();
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= n) return;
     const int wi = __float_as_int(spt[p].w);
@@ -352,9 +366,10 @@ __global__ __launch_bounds__(TPB) void k_compress(const float4* __restrict__ spt
 }
 
 // HP: lab = root (general mode: also register the smallest same-class HP of the component)
-__global__ __launch_bounds__(TPB) void k_flatten(const float4* __restrict__ spt, int n, int* __restrict__ parent,
+__global__ __launch_bounds__(TPB) void k_flatten(const float4* __restrict__ spt, NRef n_ref, int* __restrict__ parent,
                                                 const int* __restrict__ sem, int general, int* __restrict__ semseed,
                                                 int* __restrict__ lab) {
+    const int n = n_ref.get();
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= n) return;
     const int wi = __float_as_int(spt[p].w);
@@ -366,8 +381,9 @@ __global__ __launch_bounds__(TPB) void k_flatten(const float4* __restrict__ spt,
 }
 
 // general mode: HP label = seed of (component, class)
-__global__ __launch_bounds__(TPB) void k_hp_seed_general(const float4* __restrict__ spt, int n, const int* __restrict__ sem,
+__global__ __launch_bounds__(TPB) void k_hp_seed_general(const float4* __restrict__ spt, NRef n_ref, const int* __restrict__ sem,
                                                         const int* __restrict__ semseed, int* __restrict__ lab) {
+    const int n = n_ref.get();
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= n) return;
     const int wi = __float_as_int(spt[p].w);
@@ -380,12 +396,13 @@ __global__ __launch_bounds__(TPB) void k_hp_seed_general(const float4* __restric
 // clusters (component of an adjacent HP, class of the LP) -- binary.cu:206-209.  `root` holds component roots of HPs.
 // All HPs of a trusted cell share one component, so the cell contributes one candidate seed: it is skipped when that
 // seed cannot raise the maximum, taken without any distance test in the LP's own cell, and otherwise needs one witness.
-__global__ __launch_bounds__(TPB) void k_border(const float4* __restrict__ spt, const int* __restrict__ sseg, int n,
+__global__ __launch_bounds__(TPB) void k_border(const float4* __restrict__ spt, const int* __restrict__ sseg, NRef n_ref,
                                                float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
                                                unsigned hmask, const int* __restrict__ hstart,
                                                const int* __restrict__ hcount, const int* __restrict__ sem, int general,
                                                const int* __restrict__ semseed, const int* __restrict__ root,
                                                int* __restrict__ lab, const int* __restrict__ cell_rep) {
+    const int n = n_ref.get();
     const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
     int p = (int)(t / NB_Q);
     const int q = (int)(t % NB_Q);
@@ -440,13 +457,15 @@ __global__ __launch_bounds__(TPB) void k_border(const float4* __restrict__ spt, 
     if (live && q == 0) lab[i] = best;
 }
 
-__global__ __launch_bounds__(TPB) void k_copy_i32(const int* __restrict__ src, int* __restrict__ dst, int n) {
+__global__ __launch_bounds__(TPB) void k_copy_i32(const int* __restrict__ src, int* __restrict__ dst, NRef n_ref) {
+    const int n = n_ref.get();
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i < n) dst[i] = src[i];
 }
 
 // a14: cluster population (HPs + border LPs) per seed
-__global__ __launch_bounds__(TPB) void k_sizes(const int* __restrict__ lab, int n, int* __restrict__ size) {
+__global__ __launch_bounds__(TPB) void k_sizes(const int* __restrict__ lab, NRef n_ref, int* __restrict__ size) {
+    const int n = n_ref.get();
     // a wave's lanes mostly share a handful of seeds: one atomic per distinct seed per wave instead of one per point
     const int i = blockIdx.x * TPB + threadIdx.x;
     int s = (i < n) ? lab[i] : -1;
@@ -462,7 +481,8 @@ __global__ __launch_bounds__(TPB) void k_sizes(const int* __restrict__ lab, int 
 
 // a14: keep flag per seed: dropped iff float(size) < mean_count[sem-2] * para_f (binary.cu:255-256)
 __global__ __launch_bounds__(TPB) void k_keep(const int* __restrict__ lab, const int* __restrict__ size,
-                                             const int* __restrict__ sem, int n, float para_f, int* __restrict__ keep) {
+                                             const int* __restrict__ sem, NRef n_ref, float para_f, int* __restrict__ keep) {
+    const int n = n_ref.get();
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     int k = 0;
@@ -478,11 +498,13 @@ __global__ __launch_bounds__(TPB) void k_keep(const int* __restrict__ lab, const
 __global__ __launch_bounds__(TPB) void k_relabel(const int* __restrict__ lab, const int* __restrict__ keep,
                                                 const int* __restrict__ newid, const int* __restrict__ sem,
                                                 const int* __restrict__ seg_of_pt, const float* __restrict__ org_xyz,
-                                                int n, int* __restrict__ lab2, int* __restrict__ cluster_id,
+                                                NRef n_ref, int* __restrict__ lab2, int* __restrict__ cluster_id,
                                                 int* __restrict__ clt_sem, int* __restrict__ clt_seg,
                                                 int* __restrict__ last_assigned, int* __restrict__ fsize,
                                                 int* __restrict__ noise_flag, float4* __restrict__ cand,
                                                 const int* __restrict__ size) {
+    const int n = n_ref.get();
+    if (n <= 0) return;   // capacity mode with nothing selected
     int i = blockIdx.x * TPB + threadIdx.x;
     const bool live = i < n;
     if (!live) i = n - 1;  // keep whole waves alive for the shuffles below; duplicates of the last point are harmless
@@ -516,9 +538,10 @@ __global__ __launch_bounds__(TPB) void k_relabel(const int* __restrict__ lab, co
                               __int_as_float(id >= 0 ? ((seg_of_pt[i] << 8) | sem[i]) : -1));
 }
 
-__global__ void k_cluster_num(const int* __restrict__ newid, const int* __restrict__ seg_off, int n_seg, int n,
+__global__ void k_cluster_num(const int* __restrict__ newid, const int* __restrict__ seg_off, int n_seg, NRef n_ref,
                               const int* __restrict__ total, int* __restrict__ cluster_num,
                               const int* __restrict__ status, int* __restrict__ n_clusters) {
+    const int n = n_ref.get();
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0) *n_clusters = (*status != 0) ? -1 : *total;
     if (b >= n_seg) return;
@@ -529,7 +552,8 @@ __global__ void k_cluster_num(const int* __restrict__ newid, const int* __restri
 }
 
 __global__ __launch_bounds__(TPB) void k_compact_noise(const int* __restrict__ noise_flag, const int* __restrict__ pos,
-                                                      int n, int* __restrict__ noise_list) {
+                                                      NRef n_ref, int* __restrict__ noise_list) {
+    const int n = n_ref.get();
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i < n && noise_flag[i]) noise_list[pos[i]] = i;
 }
@@ -739,10 +763,12 @@ extern "C" size_t pbn_cluster_workspace_bytes(int n_points, int n_segments, int 
 
 extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, const int32_t* sem,
                                   const int32_t* seg_len, int n, int n_seg, float radius, int min_pts, float para_f,
-                                  int nv_flag, int general, int32_t* cluster_id, int32_t* cluster_num, int32_t* den,
+                                  int nv_flag, int flags, int32_t* cluster_id, int32_t* cluster_num, int32_t* den,
                                   float* centers, int32_t* clt_sem, int32_t* n_clusters, int32_t* member_start,
                                   int32_t* member_idx, void* workspace, size_t workspace_bytes, pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const int general = flags & 1;
+    const int capacity = (flags >> 1) & 1;   // n is a capacity; the points that exist are the first sum(seg_len) rows
     if (n < 0 || n_seg < 0 || n_seg > 65535 || !(radius > 0.0f) || !n_clusters || (n_seg > 0 && !cluster_num))
         return PBN_ERR_ARG;
     if ((member_start == nullptr) != (member_idx == nullptr)) return PBN_ERR_ARG;
@@ -764,6 +790,7 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
     const float r2 = radius * radius;      // binary_cuda_functions.cu:85 (fp32 product)
     const unsigned hmask = w.hcap - 1;
     const int nb = cdiv(n, TPB);
+    const NRef nr{n, capacity ? w.seg_off + n_seg : nullptr};
     int* status = w.scalars + 0;
     int* total_kept = w.scalars + 1;
     int* n_noise = w.scalars + 2;
@@ -777,42 +804,46 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
         PBN_HIP_CHECK(hipMemsetAsync(z0, 0, (size_t)(base + w.zero_end - z0), stream));
         PBN_HIP_CHECK(hipMemsetAsync(f0, 0xff, (size_t)(base + w.ff_end - f0), stream));
         PBN_HIP_CHECK(hipMemsetAsync(b0, 0x7f, (size_t)(base + w.big_end - b0), stream));
+        if (capacity) {   // the scans below run over the whole capacity: flags of rows that do not exist must read 0
+            PBN_HIP_CHECK(hipMemsetAsync(w.keep, 0, sizeof(int) * (size_t)n, stream));
+            PBN_HIP_CHECK(hipMemsetAsync(w.noise_flag, 0, sizeof(int) * (size_t)n, stream));
+        }
     }
 
-    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(64), 0, stream, seg_len, n_seg, n, w.seg_off, status);
-    hipLaunchKernelGGL(k_cell_insert, dim3(nb), dim3(TPB), 0, stream, off_xyz, sem, w.seg_off, n_seg, n, inv_cell,
+    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(64), 0, stream, seg_len, n_seg, n, capacity, w.seg_off, status);
+    hipLaunchKernelGGL(k_cell_insert, dim3(nb), dim3(TPB), 0, stream, off_xyz, sem, w.seg_off, n_seg, nr, inv_cell,
                        w.hkeys, w.hcount, hmask, w.slot_of_pt, w.seg_of_pt, status);
     int rc = scan_exclusive_i32(w.hcount, w.hstart, (int)w.hcap, w.scan_tmp, nullptr, stream);
     if (rc != PBN_OK) return rc;
-    hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(TPB), 0, stream, off_xyz, n, w.slot_of_pt, w.hstart, w.hcursor,
+    hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(TPB), 0, stream, off_xyz, nr, w.slot_of_pt, w.hstart, w.hcursor,
                        w.seg_of_pt, w.spt, w.sseg, w.sslot);
-    hipLaunchKernelGGL(k_count, dim3(cdiv((long long)n * NB_Q, TPB)), dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+    hipLaunchKernelGGL(k_count, dim3(cdiv((long long)n * NB_Q, TPB)), dim3(TPB), 0, stream, w.spt, w.sseg, nr, inv_cell, r2, w.hkeys, hmask,
                        w.hstart, w.hcount, den);
-    hipLaunchKernelGGL(k_tag_hp, dim3(nb), dim3(TPB), 0, stream, w.spt, n, den, min_pts, w.parent, w.lab, w.sslot, w.cell_rep);
+    hipLaunchKernelGGL(k_tag_hp, dim3(nb), dim3(TPB), 0, stream, w.spt, nr, den, min_pts, w.parent, w.lab, w.sslot, w.cell_rep);
     const dim3 nbq(cdiv((long long)n * NB_Q, TPB));
-    hipLaunchKernelGGL(k_union, nbq, dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+    hipLaunchKernelGGL(k_union, nbq, dim3(TPB), 0, stream, w.spt, w.sseg, nr, inv_cell, r2, w.hkeys, hmask,
                        w.hstart, w.hcount, w.parent, w.cell_rep, w.sslot, 0);
-    hipLaunchKernelGGL(k_compress, dim3(nb), dim3(TPB), 0, stream, w.spt, n, w.parent);
-    hipLaunchKernelGGL(k_union, nbq, dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+    hipLaunchKernelGGL(k_compress, dim3(nb), dim3(TPB), 0, stream, w.spt, nr, w.parent);
+    hipLaunchKernelGGL(k_union, nbq, dim3(TPB), 0, stream, w.spt, w.sseg, nr, inv_cell, r2, w.hkeys, hmask,
                        w.hstart, w.hcount, w.parent, w.cell_rep, w.sslot, 1);
-    hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, stream, w.spt, n, w.parent, sem, general, w.semseed, w.lab);
-    hipLaunchKernelGGL(k_copy_i32, dim3(nb), dim3(TPB), 0, stream, w.lab, w.root, n);
+    hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, stream, w.spt, nr, w.parent, sem, general, w.semseed, w.lab);
+    hipLaunchKernelGGL(k_copy_i32, dim3(nb), dim3(TPB), 0, stream, w.lab, w.root, nr);
     if (general)
-        hipLaunchKernelGGL(k_hp_seed_general, dim3(nb), dim3(TPB), 0, stream, w.spt, n, sem, w.semseed, w.lab);
-    hipLaunchKernelGGL(k_border, nbq, dim3(TPB), 0, stream, w.spt, w.sseg, n, inv_cell, r2, w.hkeys, hmask,
+        hipLaunchKernelGGL(k_hp_seed_general, dim3(nb), dim3(TPB), 0, stream, w.spt, nr, sem, w.semseed, w.lab);
+    hipLaunchKernelGGL(k_border, nbq, dim3(TPB), 0, stream, w.spt, w.sseg, nr, inv_cell, r2, w.hkeys, hmask,
                        w.hstart, w.hcount, sem, general, w.semseed, w.root, w.lab, w.cell_rep);
-    hipLaunchKernelGGL(k_sizes, dim3(nb), dim3(TPB), 0, stream, w.lab, n, w.size);
-    hipLaunchKernelGGL(k_keep, dim3(nb), dim3(TPB), 0, stream, w.lab, w.size, sem, n, para_f, w.keep);
+    hipLaunchKernelGGL(k_sizes, dim3(nb), dim3(TPB), 0, stream, w.lab, nr, w.size);
+    hipLaunchKernelGGL(k_keep, dim3(nb), dim3(TPB), 0, stream, w.lab, w.size, sem, nr, para_f, w.keep);
     rc = scan_exclusive_i32(w.keep, w.newid, n, w.scan_tmp, total_kept, stream);
     if (rc != PBN_OK) return rc;
-    hipLaunchKernelGGL(k_relabel, dim3(nb), dim3(TPB), 0, stream, w.lab, w.keep, w.newid, sem, w.seg_of_pt, org_xyz, n,
+    hipLaunchKernelGGL(k_relabel, dim3(nb), dim3(TPB), 0, stream, w.lab, w.keep, w.newid, sem, w.seg_of_pt, org_xyz, nr,
                        w.lab2, cluster_id, clt_sem, w.clt_seg, w.last_assigned, w.fsize, w.noise_flag, w.cand, w.size);
-    hipLaunchKernelGGL(k_cluster_num, dim3(cdiv(n_seg, 64)), dim3(64), 0, stream, w.newid, w.seg_off, n_seg, n,
+    hipLaunchKernelGGL(k_cluster_num, dim3(cdiv(n_seg, 64)), dim3(64), 0, stream, w.newid, w.seg_off, n_seg, nr,
                        total_kept, cluster_num, status, n_clusters);
     if (nv_flag) {
         rc = scan_exclusive_i32(w.noise_flag, w.noise_pos, n, w.scan_tmp, n_noise, stream);
         if (rc != PBN_OK) return rc;
-        hipLaunchKernelGGL(k_compact_noise, dim3(nb), dim3(TPB), 0, stream, w.noise_flag, w.noise_pos, n, w.noise_list);
+        hipLaunchKernelGGL(k_compact_noise, dim3(nb), dim3(TPB), 0, stream, w.noise_flag, w.noise_pos, nr, w.noise_list);
         hipLaunchKernelGGL(k_noise_nn, dim3(cdiv((long long)n * 64, TPB)), dim3(TPB), 0, stream, w.noise_list, n_noise, w.cand, sem, w.seg_of_pt,
                            w.seg_off, w.lab2, w.last_assigned, cluster_id, w.fsize);
     }

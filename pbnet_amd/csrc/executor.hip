@@ -118,8 +118,8 @@ extern "C" size_t pbn_coords_prepare_bytes(int n, int want_k5, pbn_prepare_layou
     return off;
 }
 
-extern "C" int pbn_coords_prepare(const int32_t* coords, int n, int want_k5, int x_fastest, void* arena, size_t arena_bytes,
-                                  const pbn_prepare_layout* P, pbn_stream_t stream) {
+static int coords_prepare_impl(const int32_t* coords, const int32_t* n_dev, int n, int want_k5, int x_fastest, void* arena,
+                               size_t arena_bytes, const pbn_prepare_layout* P, pbn_stream_t stream) {
     if (n < 0 || !arena || !P) return PBN_ERR_ARG;
     pbn_prepare_layout chk;
     if (pbn_coords_prepare_bytes(n, want_k5, &chk) > arena_bytes) return PBN_ERR_WORKSPACE;
@@ -139,7 +139,7 @@ extern "C" int pbn_coords_prepare(const int32_t* coords, int n, int want_k5, int
     if (!coords) return PBN_ERR_ARG;
     int32_t* n_unique = I(P->n_unique);
     // 1. de-duplication in the external (first occurrence, ascending) order
-    int rc = coords_unique_impl(coords, nullptr, n, (uint64_t*)(A + P->tmp_keys), I(P->tmp_vals), pbn_hash_capacity(n),
+    int rc = coords_unique_impl(coords, n_dev, n, (uint64_t*)(A + P->tmp_keys), I(P->tmp_vals), pbn_hash_capacity(n),
                                 I(P->uidx32), I(P->inv32), I(P->ucoords), n_unique, A + L->workspace,
                                 (size_t)L->workspace_bytes, n_unique + 8, false, st);
     if (rc != PBN_OK) return rc;
@@ -162,6 +162,18 @@ extern "C" int pbn_coords_prepare(const int32_t* coords, int n, int want_k5, int
     return coords_build_upper(n, want_k5, x_fastest, arena, L, st);
 }
 
+extern "C" int pbn_coords_prepare(const int32_t* coords, int n, int want_k5, int x_fastest, void* arena, size_t arena_bytes,
+                                  const pbn_prepare_layout* P, pbn_stream_t stream) {
+    return coords_prepare_impl(coords, nullptr, n, want_k5, x_fastest, arena, arena_bytes, P, stream);
+}
+
+// capacity form: the input holds *n_dev (<= n_cap) rows, a count that stays on the device
+extern "C" int pbn_coords_prepare_dev(const int32_t* coords, const int32_t* n_dev, int n_cap, int want_k5, int x_fastest,
+                                      void* arena, size_t arena_bytes, const pbn_prepare_layout* P, pbn_stream_t stream) {
+    if (!n_dev) return PBN_ERR_ARG;
+    return coords_prepare_impl(coords, n_dev, n_cap, want_k5, x_fastest, arena, arena_bytes, P, stream);
+}
+
 static inline int esize(int dtype) { return dtype == PBN_F32 ? 4 : 2; }
 
 extern "C" size_t pbn_unet_arena_bytes(const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows, int dtype,
@@ -181,7 +193,7 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
                              const int32_t* n_rows, const void* input, int ld_input, const int32_t* const* k3,
                              const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
                              size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream,
-                             hipEvent_t* events) {
+                             hipEvent_t* events, const int32_t* n_rows_dev = nullptr) {
     if (!ops || !bufs || !n_rows || !input || !arena || n_ops < 1 || n_bufs < 2 || n_bufs > 512) return PBN_ERR_ARG;
     int64_t offs[512];
     if (pbn_unet_arena_bytes(bufs, n_bufs, n_rows, dtype, offs) > arena_bytes) return PBN_ERR_WORKSPACE;
@@ -209,7 +221,8 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
         void* out = base(o.out_buf) + (size_t)o.out_col * es;
         const void* res = o.res_buf >= 0 ? base(o.res_buf) + (size_t)o.res_col * es : nullptr;
         if (events) PBN_HIP_CHECK(hipEventRecord(events[2 * i], (hipStream_t)stream));
-        const int rc = pbn_spconv_forward(in, ld(o.in_buf), n_rows[o.level_in], nbr, K, nullptr, nullptr, n_rows[o.level_out], o.w, o.vpo,
+        const int rc = pbn_spconv_forward(in, ld(o.in_buf), n_rows[o.level_in], nbr, K, nullptr,
+                                          n_rows_dev ? n_rows_dev + o.level_out : nullptr, n_rows[o.level_out], o.w, o.vpo,
                                           o.n_steps, o.cout_p, o.scale, o.shift, res, o.res_buf >= 0 ? ld(o.res_buf) : 0,
                                           o.relu, out, ld(o.out_buf), dtype, 0, splitk_ws, splitk_bytes, stream);
         if (rc != PBN_OK) return rc;
@@ -224,6 +237,18 @@ extern "C" int pbn_unet_forward(const pbn_unet_op* ops, int n_ops, const pbn_une
                                 size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream) {
     return unet_forward_impl(ops, n_ops, bufs, n_bufs, n_rows, input, ld_input, k3, k5, down, up, arena, arena_bytes, dtype,
                              splitk_ws, splitk_bytes, stream, nullptr);
+}
+
+// capacity form: n_rows are capacities, the rows that exist are n_rows_dev[level] (device); launches are sized by the
+// capacities and every kernel bounds itself by the device-side count
+extern "C" int pbn_unet_forward_dev(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs,
+                                    const int32_t* n_rows_cap, const int32_t* n_rows_dev, const void* input, int ld_input,
+                                    const int32_t* const* k3, const int32_t* k5, const int32_t* const* down,
+                                    const int32_t* const* up, void* arena, size_t arena_bytes, int dtype, void* splitk_ws,
+                                    size_t splitk_bytes, pbn_stream_t stream) {
+    if (!n_rows_dev) return PBN_ERR_ARG;
+    return unet_forward_impl(ops, n_ops, bufs, n_bufs, n_rows_cap, input, ld_input, k3, k5, down, up, arena, arena_bytes, dtype,
+                             splitk_ws, splitk_bytes, stream, nullptr, n_rows_dev);
 }
 
 // Measurement variant: brackets every op with HIP events on the launching stream, SYNCHRONISES the stream at the end and

@@ -30,11 +30,14 @@ __device__ __forceinline__ int upper_entry(const int* __restrict__ start, int n,
 template <int ESZ>
 __global__ __launch_bounds__(TPB) void k_local_scene_rows(
     const int* __restrict__ ent_row_start, const int* __restrict__ ent_member_start, const int* __restrict__ ent_scene,
-    const float* __restrict__ ent_weight, int n_ent, int n_rows, const int* __restrict__ member_idx,
+    const float* __restrict__ ent_weight, int n_ent_cap, int n_rows_cap, const int* __restrict__ n_ent_dev,
+    const int* __restrict__ n_rows_dev, const int* __restrict__ member_idx,
     const long long* __restrict__ ins_ind, const float* __restrict__ xyz, float inv_voxel,
     const unsigned char* __restrict__ point_feat, int ld_feat, int channels, const unsigned char* __restrict__ sem_score,
     int ld_sem, const long long* __restrict__ sem_pred, int dtype, long long* __restrict__ point_idx,
     long long* __restrict__ row_scene, int* __restrict__ coords, unsigned* __restrict__ feat_out, int words_per_row) {
+    const int n_ent = n_ent_dev ? min(*n_ent_dev, n_ent_cap) : n_ent_cap;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_cap) : n_rows_cap;
     const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
     if (e >= (long long)n_rows * words_per_row) return;
     const int r = (int)(e / words_per_row), w = (int)(e - (long long)r * words_per_row);
@@ -74,13 +77,20 @@ __global__ __launch_bounds__(TPB) void k_local_scene_rows(
 
 // ---- out[i, :C] = in[idx[i], :C], out[i, C:ld_out] = 0  (32-bit words) -----------------------------------------------
 __global__ __launch_bounds__(TPB) void k_gather_pad_rows(const unsigned* __restrict__ in, int ld_in_w, int row_w,
-                                                        const long long* __restrict__ idx, int n,
-                                                        unsigned* __restrict__ out, int ld_out_w) {
+                                                        const long long* __restrict__ idx,
+                                                        const long long* __restrict__ idx2, int n_cap,
+                                                        const int* __restrict__ n_dev, unsigned* __restrict__ out,
+                                                        int ld_out_w) {
+    const int n = n_dev ? min(*n_dev, n_cap) : n_cap;
     const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
     if (e >= (long long)n * ld_out_w) return;
     const int i = (int)(e / ld_out_w), w = (int)(e - (long long)i * ld_out_w);
     unsigned v = 0;
-    if (w < row_w) v = in[(size_t)(idx ? idx[i] : i) * ld_in_w + w];
+    if (w < row_w) {
+        long long r = idx ? idx[i] : i;
+        if (idx2) r = idx2[r];
+        v = in[(size_t)r * ld_in_w + w];
+    }
     out[e] = v;
 }
 
@@ -121,12 +131,14 @@ template <> struct RowIO<__half> {
 
 template <typename T, int C, int H>
 __global__ __launch_bounds__(TPB) void k_mlp_rows(const T* __restrict__ in, int ld_in, const long long* __restrict__ idx_a,
-                                                 const long long* __restrict__ idx_b, int n,
+                                                 const long long* __restrict__ idx_b, int n_cap,
+                                                 const int* __restrict__ n_dev,
                                                  const float* __restrict__ w1, const float* __restrict__ scale,
                                                  const float* __restrict__ shift, const float* __restrict__ slope,
                                                  const float* __restrict__ w2, const float* __restrict__ b2, int n_out,
                                                  int sigmoid, T* __restrict__ out, int ld_out) {
     constexpr int E = RowIO<T>::E;
+    const int n = n_dev ? min(*n_dev, n_cap) : n_cap;
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     long long row = idx_a ? idx_a[i] : i;
@@ -282,8 +294,10 @@ template <> __device__ __forceinline__ float ld_f32<__half>(const __half* p) { r
 // pass 1: kept rows per block of SEL_BLOCK rows and per local scene (wave-aggregated atomics: rows are grouped by scene)
 template <typename T>
 __global__ __launch_bounds__(TPB) void k_mask_count(const T* __restrict__ score, int ld, float thd,
-                                                   const long long* __restrict__ row_scene, int n, int n_scenes,
+                                                   const long long* __restrict__ row_scene, int n_cap,
+                                                   const int* __restrict__ n_dev, int n_scenes,
                                                    int* __restrict__ per_scene, int* __restrict__ block_cnt) {
+    const int n = n_dev ? min(*n_dev, n_cap) : n_cap;
     __shared__ int s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
@@ -314,13 +328,15 @@ __global__ __launch_bounds__(TPB) void k_mask_count(const T* __restrict__ score,
 template <typename T>
 __global__ __launch_bounds__(TPB) void k_proposal_rows(const T* __restrict__ score, int ld, float thd,
                                                       const long long* __restrict__ row_scene,
-                                                      const long long* __restrict__ point_idx, int n,
+                                                      const long long* __restrict__ point_idx, int n_cap,
+                                                      const int* __restrict__ n_dev,
                                                       const int* __restrict__ dense_of, const int* __restrict__ block_cnt,
                                                       const float* __restrict__ xyz, float scale, float inv_voxel,
                                                       const uint4* __restrict__ point_feat, int ld_feat_vec, int vpr,
                                                       long long* __restrict__ prop_idx, T* __restrict__ prop_ms,
                                                       int* __restrict__ coords, uint4* __restrict__ feat) {
     constexpr int PER = SEL_BLOCK / TPB;
+    const int n = n_dev ? min(*n_dev, n_cap) : n_cap;
     __shared__ int wtot[TPB / 64];
     __shared__ int s_base;
     int part = 0;
@@ -424,8 +440,9 @@ __global__ __launch_bounds__(TPB) void k_pack_weight(const float* __restrict__ s
 
 using namespace pbn;
 
-extern "C" int pbn_local_scene_rows(const int32_t* ent_row_start, const int32_t* ent_member_start,
+static int local_scene_rows_impl(const int32_t* ent_row_start, const int32_t* ent_member_start,
                                     const int32_t* ent_scene, const float* ent_weight, int n_ent, int n_rows,
+                                    const int32_t* n_ent_dev, const int32_t* n_rows_dev,
                                     const int32_t* member_idx, const int64_t* ins_ind, const float* xyz, float inv_voxel,
                                     const void* point_feat, int ld_feat, int channels, const void* sem_score, int ld_sem,
                                     const int64_t* sem_pred, int dtype, int64_t* point_idx, int64_t* row_scene,
@@ -442,7 +459,8 @@ extern "C" int pbn_local_scene_rows(const int32_t* ent_row_start, const int32_t*
     const long long total = (long long)n_rows * wpr;
     const dim3 grid(cdiv(total, TPB));
 #define PBN_ARGS                                                                                                        \
-    ent_row_start, ent_member_start, ent_scene, ent_weight, n_ent, n_rows, member_idx, (const long long*)ins_ind, xyz,   \
+    ent_row_start, ent_member_start, ent_scene, ent_weight, n_ent, n_rows, n_ent_dev, n_rows_dev, member_idx,            \
+        (const long long*)ins_ind, xyz,                                                                                  \
         inv_voxel, (const unsigned char*)point_feat, ld_feat, channels, (const unsigned char*)sem_score, ld_sem,         \
         (const long long*)sem_pred, dtype, (long long*)point_idx, (long long*)row_scene, coords, (unsigned*)feat_out, wpr
     if (esz == 4) hipLaunchKernelGGL(k_local_scene_rows<4>, grid, dim3(TPB), 0, stream, PBN_ARGS);
@@ -452,8 +470,32 @@ extern "C" int pbn_local_scene_rows(const int32_t* ent_row_start, const int32_t*
     return PBN_OK;
 }
 
-extern "C" int pbn_gather_pad_rows(const void* in, int ld_in_bytes, int row_bytes, const int64_t* idx, int n, void* out,
-                                   int ld_out_bytes, pbn_stream_t stream_) {
+extern "C" int pbn_local_scene_rows(const int32_t* ent_row_start, const int32_t* ent_member_start,
+                                    const int32_t* ent_scene, const float* ent_weight, int n_ent, int n_rows,
+                                    const int32_t* member_idx, const int64_t* ins_ind, const float* xyz, float inv_voxel,
+                                    const void* point_feat, int ld_feat, int channels, const void* sem_score, int ld_sem,
+                                    const int64_t* sem_pred, int dtype, int64_t* point_idx, int64_t* row_scene,
+                                    int32_t* coords, void* feat_out, int ld_out, pbn_stream_t stream) {
+    return local_scene_rows_impl(ent_row_start, ent_member_start, ent_scene, ent_weight, n_ent, n_rows, nullptr, nullptr,
+                                 member_idx, ins_ind, xyz, inv_voxel, point_feat, ld_feat, channels, sem_score, ld_sem,
+                                 sem_pred, dtype, point_idx, row_scene, coords, feat_out, ld_out, stream);
+}
+
+extern "C" int pbn_local_scene_rows_dev(const int32_t* ent_row_start, const int32_t* ent_member_start,
+                                        const int32_t* ent_scene, const float* ent_weight, int n_ent_cap, int n_rows_cap,
+                                        const int32_t* n_ent_dev, const int32_t* n_rows_dev, const int32_t* member_idx,
+                                        const int64_t* ins_ind, const float* xyz, float inv_voxel, const void* point_feat,
+                                        int ld_feat, int channels, const void* sem_score, int ld_sem,
+                                        const int64_t* sem_pred, int dtype, int64_t* point_idx, int64_t* row_scene,
+                                        int32_t* coords, void* feat_out, int ld_out, pbn_stream_t stream) {
+    if (!n_ent_dev || !n_rows_dev) return PBN_ERR_ARG;
+    return local_scene_rows_impl(ent_row_start, ent_member_start, ent_scene, ent_weight, n_ent_cap, n_rows_cap, n_ent_dev,
+                                 n_rows_dev, member_idx, ins_ind, xyz, inv_voxel, point_feat, ld_feat, channels, sem_score,
+                                 ld_sem, sem_pred, dtype, point_idx, row_scene, coords, feat_out, ld_out, stream);
+}
+
+static int gather_pad_rows_impl(const void* in, int ld_in_bytes, int row_bytes, const int64_t* idx, const int64_t* idx2,
+                                int n, const int32_t* n_dev, void* out, int ld_out_bytes, pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0 || row_bytes <= 0 || (row_bytes & 3) || (ld_in_bytes & 3) || (ld_out_bytes & 3) || ld_out_bytes < row_bytes ||
         ld_in_bytes < row_bytes)
@@ -462,13 +504,25 @@ extern "C" int pbn_gather_pad_rows(const void* in, int ld_in_bytes, int row_byte
     if (!in || !out || (((uintptr_t)in | (uintptr_t)out) & 3)) return PBN_ERR_ARG;
     const long long total = (long long)n * (ld_out_bytes / 4);
     hipLaunchKernelGGL(k_gather_pad_rows, dim3(cdiv(total, TPB)), dim3(TPB), 0, stream, (const unsigned*)in, ld_in_bytes / 4,
-                       row_bytes / 4, (const long long*)idx, n, (unsigned*)out, ld_out_bytes / 4);
+                       row_bytes / 4, (const long long*)idx, (const long long*)idx2, n, n_dev, (unsigned*)out,
+                       ld_out_bytes / 4);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
 
-extern "C" int pbn_mlp_rows(const void* in, int ld_in, int channels, const int64_t* idx_a, const int64_t* idx_b, int n,
-                            const float* w1, const float* scale, const float* shift, const float* slope, int hidden,
+extern "C" int pbn_gather_pad_rows(const void* in, int ld_in_bytes, int row_bytes, const int64_t* idx, int n, void* out,
+                                   int ld_out_bytes, pbn_stream_t stream) {
+    return gather_pad_rows_impl(in, ld_in_bytes, row_bytes, idx, nullptr, n, nullptr, out, ld_out_bytes, stream);
+}
+
+extern "C" int pbn_gather_pad_rows_dev(const void* in, int ld_in_bytes, int row_bytes, const int64_t* idx,
+                                       const int64_t* idx2, int n_cap, const int32_t* n_dev, void* out, int ld_out_bytes,
+                                       pbn_stream_t stream) {
+    return gather_pad_rows_impl(in, ld_in_bytes, row_bytes, idx, idx2, n_cap, n_dev, out, ld_out_bytes, stream);
+}
+
+static int mlp_rows_impl(const void* in, int ld_in, int channels, const int64_t* idx_a, const int64_t* idx_b, int n,
+                            const int32_t* n_dev, const float* w1, const float* scale, const float* shift, const float* slope, int hidden,
                             const float* w2, const float* b2, int n_out, int sigmoid, void* out, int ld_out, int dtype,
                             pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -481,7 +535,8 @@ extern "C" int pbn_mlp_rows(const void* in, int ld_in, int channels, const int64
     const dim3 grid(cdiv(n, TPB));
 #define PBN_MLP(TT, HH)                                                                                                 \
     hipLaunchKernelGGL((k_mlp_rows<TT, 32, HH>), grid, dim3(TPB), 0, stream, (const TT*)in, ld_in,                        \
-                       (const long long*)idx_a, (const long long*)idx_b, n, w1, scale, shift, slope, w2, b2, n_out,      \
+                       (const long long*)idx_a, (const long long*)idx_b, n, n_dev, w1, scale, shift, slope, w2, b2,      \
+                       n_out,                                                                                            \
                        sigmoid, (TT*)out, ld_out)
     if (dtype == PBN_F32) { if (hidden == 16) PBN_MLP(float, 16); else PBN_MLP(float, 32); }
     else if (dtype == PBN_BF16) { if (hidden == 16) PBN_MLP(__hip_bfloat16, 16); else PBN_MLP(__hip_bfloat16, 32); }
@@ -490,6 +545,22 @@ extern "C" int pbn_mlp_rows(const void* in, int ld_in, int channels, const int64
 #undef PBN_MLP
     PBN_LAUNCH_CHECK();
     return PBN_OK;
+}
+
+extern "C" int pbn_mlp_rows(const void* in, int ld_in, int channels, const int64_t* idx_a, const int64_t* idx_b, int n,
+                            const float* w1, const float* scale, const float* shift, const float* slope, int hidden,
+                            const float* w2, const float* b2, int n_out, int sigmoid, void* out, int ld_out, int dtype,
+                            pbn_stream_t stream) {
+    return mlp_rows_impl(in, ld_in, channels, idx_a, idx_b, n, nullptr, w1, scale, shift, slope, hidden, w2, b2, n_out,
+                         sigmoid, out, ld_out, dtype, stream);
+}
+
+extern "C" int pbn_mlp_rows_dev(const void* in, int ld_in, int channels, const int64_t* idx_a, const int64_t* idx_b,
+                                int n_cap, const int32_t* n_dev, const float* w1, const float* scale, const float* shift,
+                                const float* slope, int hidden, const float* w2, const float* b2, int n_out, int sigmoid,
+                                void* out, int ld_out, int dtype, pbn_stream_t stream) {
+    return mlp_rows_impl(in, ld_in, channels, idx_a, idx_b, n_cap, n_dev, w1, scale, shift, slope, hidden, w2, b2, n_out,
+                         sigmoid, out, ld_out, dtype, stream);
 }
 
 extern "C" int pbn_select_blocks(int n) { return n > 0 ? cdiv(n, SEL_BLOCK) : 0; }
@@ -546,8 +617,9 @@ extern "C" int pbn_select_points(const int64_t* sem_pred, int n, int n_cls, cons
     return PBN_OK;
 }
 
-extern "C" int pbn_mask_count(const void* mask_score, int ld, float thd, const int64_t* row_scene, int n, int n_scenes,
-                              int dtype, int32_t* per_scene, int32_t* block_cnt, pbn_stream_t stream_) {
+static int mask_count_impl(const void* mask_score, int ld, float thd, const int64_t* row_scene, int n,
+                           const int32_t* n_dev, int n_scenes, int dtype, int32_t* per_scene, int32_t* block_cnt,
+                           pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0 || n_scenes < 0 || ld < 1) return PBN_ERR_ARG;
     if (n_scenes > 0) {
@@ -559,21 +631,33 @@ extern "C" int pbn_mask_count(const void* mask_score, int ld, float thd, const i
     const dim3 grid(cdiv(n, SEL_BLOCK));
     if (dtype == PBN_F32)
         hipLaunchKernelGGL(k_mask_count<float>, grid, dim3(TPB), 0, stream, (const float*)mask_score, ld, thd,
-                           (const long long*)row_scene, n, n_scenes, per_scene, block_cnt);
+                           (const long long*)row_scene, n, n_dev, n_scenes, per_scene, block_cnt);
     else if (dtype == PBN_BF16)
         hipLaunchKernelGGL(k_mask_count<__hip_bfloat16>, grid, dim3(TPB), 0, stream, (const __hip_bfloat16*)mask_score, ld,
-                           thd, (const long long*)row_scene, n, n_scenes, per_scene, block_cnt);
+                           thd, (const long long*)row_scene, n, n_dev, n_scenes, per_scene, block_cnt);
     else if (dtype == PBN_F16)
         hipLaunchKernelGGL(k_mask_count<__half>, grid, dim3(TPB), 0, stream, (const __half*)mask_score, ld, thd,
-                           (const long long*)row_scene, n, n_scenes, per_scene, block_cnt);
+                           (const long long*)row_scene, n, n_dev, n_scenes, per_scene, block_cnt);
     else
         return PBN_ERR_ARG;
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
 
-extern "C" int pbn_proposal_rows(const void* mask_score, int ld, float thd, const int64_t* row_scene,
-                                 const int64_t* point_idx, int n, const int32_t* dense_of, const int32_t* block_cnt,
+extern "C" int pbn_mask_count(const void* mask_score, int ld, float thd, const int64_t* row_scene, int n, int n_scenes,
+                              int dtype, int32_t* per_scene, int32_t* block_cnt, pbn_stream_t stream) {
+    return mask_count_impl(mask_score, ld, thd, row_scene, n, nullptr, n_scenes, dtype, per_scene, block_cnt, stream);
+}
+
+extern "C" int pbn_mask_count_dev(const void* mask_score, int ld, float thd, const int64_t* row_scene, int n_cap,
+                                  const int32_t* n_dev, int n_scenes_cap, int dtype, int32_t* per_scene, int32_t* block_cnt,
+                                  pbn_stream_t stream) {
+    return mask_count_impl(mask_score, ld, thd, row_scene, n_cap, n_dev, n_scenes_cap, dtype, per_scene, block_cnt, stream);
+}
+
+static int proposal_rows_impl(const void* mask_score, int ld, float thd, const int64_t* row_scene,
+                                 const int64_t* point_idx, int n, const int32_t* n_dev, const int32_t* dense_of,
+                                 const int32_t* block_cnt,
                                  const float* xyz, float scale, float inv_voxel, const void* point_feat, int ld_feat,
                                  int channels, int dtype, int64_t* proposals_idx, void* proposals_ms, int32_t* coords,
                                  void* feat_out, pbn_stream_t stream_) {
@@ -594,7 +678,8 @@ extern "C" int pbn_proposal_rows(const void* mask_score, int ld, float thd, cons
     const dim3 grid(cdiv(n, SEL_BLOCK));
 #define PBN_PR(TT)                                                                                                      \
     hipLaunchKernelGGL(k_proposal_rows<TT>, grid, dim3(TPB), 0, stream, (const TT*)mask_score, ld, thd,                    \
-                       (const long long*)row_scene, (const long long*)point_idx, n, dense_of, block_cnt, xyz, scale,     \
+                       (const long long*)row_scene, (const long long*)point_idx, n, n_dev, dense_of, block_cnt, xyz,     \
+                       scale,                                                                                            \
                        inv_voxel, (const uint4*)point_feat, feat_out ? ld_feat * esz / 16 : 0, vpr,                      \
                        (long long*)proposals_idx, (TT*)proposals_ms, coords, (uint4*)feat_out)
     if (dtype == PBN_F32) PBN_PR(float);
@@ -604,6 +689,26 @@ extern "C" int pbn_proposal_rows(const void* mask_score, int ld, float thd, cons
 #undef PBN_PR
     PBN_LAUNCH_CHECK();
     return PBN_OK;
+}
+
+extern "C" int pbn_proposal_rows(const void* mask_score, int ld, float thd, const int64_t* row_scene,
+                                 const int64_t* point_idx, int n, const int32_t* dense_of, const int32_t* block_cnt,
+                                 const float* xyz, float scale, float inv_voxel, const void* point_feat, int ld_feat,
+                                 int channels, int dtype, int64_t* proposals_idx, void* proposals_ms, int32_t* coords,
+                                 void* feat_out, pbn_stream_t stream) {
+    return proposal_rows_impl(mask_score, ld, thd, row_scene, point_idx, n, nullptr, dense_of, block_cnt, xyz, scale,
+                              inv_voxel, point_feat, ld_feat, channels, dtype, proposals_idx, proposals_ms, coords, feat_out,
+                              stream);
+}
+
+extern "C" int pbn_proposal_rows_dev(const void* mask_score, int ld, float thd, const int64_t* row_scene,
+                                     const int64_t* point_idx, int n_cap, const int32_t* n_dev, const int32_t* dense_of,
+                                     const int32_t* block_cnt, const float* xyz, float scale, float inv_voxel,
+                                     const void* point_feat, int ld_feat, int channels, int dtype, int64_t* proposals_idx,
+                                     void* proposals_ms, int32_t* coords, void* feat_out, pbn_stream_t stream) {
+    return proposal_rows_impl(mask_score, ld, thd, row_scene, point_idx, n_cap, n_dev, dense_of, block_cnt, xyz, scale,
+                              inv_voxel, point_feat, ld_feat, channels, dtype, proposals_idx, proposals_ms, coords, feat_out,
+                              stream);
 }
 
 // ---- rulebook pairs, offset-major (training: operands of the weight gradient) -----------------------------------------

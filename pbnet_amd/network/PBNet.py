@@ -107,6 +107,8 @@ class PBNet(nn.Module):
             inputs_v1 = ME.SparseTensor(feat_voxel, xyz_voxel)
         with section("a4_unet"):
             point_feat = self.MEUnet(inputs_v1)
+        if fused:   # data-dependent sizes of this forward (pbnet_amd.planned.measure_capacities reads them)
+            self._last_sizes = {"lv1": list(inputs_v1.coordinate_manager.row_counts())}
         _sec = section("a5_heads_gather"); _sec.__enter__()
         v2p = v2p_v1.long()
         if fused:
@@ -192,6 +194,8 @@ class PBNet(nn.Module):
             seg_len = torch.from_numpy(seg_len_h).to(dev)
         _sec.__exit__(None, None, None)
 
+        if fused:
+            self._last_sizes["points"] = int(m)
         mark("a7:select queued")
         with section("a7_16_grouping"):
             res = pbnet_ops.cluster_device(ins_offseted, ins_orig, ins_sem, seg_len, self.radius, self.min_pts)
@@ -277,6 +281,8 @@ class PBNet(nn.Module):
             point_idx, row_scene, coords, feat = stage_ops.local_scene_rows(
                 packed, n_ent, n_rows, res.member_idx, ins_ind, xyz_original, LOCAL_VOXEL, point_feat_p, sem_sfp,
                 None if fused else sem_pred_p)
+            if fused:
+                self._last_sizes.update(clusters=int(n_clt), entries=int(n_ent), rows=int(n_rows))
         else:
             ent_cluster_t = torch.from_numpy(ent_np)
             ent_rows = torch.from_numpy(sizes.astype(np.int64))[ent_cluster_t]
@@ -306,6 +312,8 @@ class PBNet(nn.Module):
         with section("a18_mask_unet"):
             if fused_glue:   # head evaluated at the rows (PBNet.py:247): same numbers as head-then-gather, one launch
                 f2, row_index = self.D_Unet(inputs_v2).rows()
+                if fused:
+                    self._last_sizes["lv2"] = list(inputs_v2.coordinate_manager.row_counts())
                 mask_score = stage_ops.mlp_rows(self.linear_binary, f2, inputs_v2.inverse_mapping, row_index)
             else:
                 mask_score = self.linear_binary(self.D_Unet(inputs_v2)).F[inputs_v2.inverse_mapping]   # [R, 1]
@@ -338,6 +346,8 @@ class PBNet(nn.Module):
             with section("a20_score_unet"):
                 if fused_glue:
                     iou_feat_f = stage_ops.mlp_rows(self.linear_IOU_feat, *self.score_Unet(inputs_v3).rows())
+                    if fused:
+                        self._last_sizes["lv3"] = list(inputs_v3.coordinate_manager.row_counts())
                 else:
                     iou_feat = self.linear_IOU_feat(self.score_Unet(inputs_v3))
             with section("a20_pool_head"):

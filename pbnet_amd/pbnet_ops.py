@@ -27,8 +27,11 @@ class ClusterResult(object):
 
 
 def cluster_device(off_xyz, org_xyz, sem, seg_len, radius, min_pts, para_f=PARA_F, nv_flag=NV_FLAG,
-                   general_sem=False, want_members=True):
+                   general_sem=False, want_members=True, capacity=False):
     """Grouping on device tensors.  off_xyz/org_xyz f32[I,3], sem i32[I], seg_len i32[B] (all CUDA).
+
+    capacity=True: the row count of the inputs is only a capacity; the points that exist are the first sum(seg_len)
+    rows (a device-side count) -- outputs beyond them are left untouched.
 
     Returns a ClusterResult of CUDA tensors; nothing is copied to the host and the stream is not synchronised.
     ``den`` is the neighbour count excluding self (binary.cu:148); ``cluster`` below adds the +1 of pbnet_ops.py:75.
@@ -54,7 +57,7 @@ def cluster_device(off_xyz, org_xyz, sem, seg_len, radius, min_pts, para_f=PARA_
     ws_bytes = lib.pbn_cluster_workspace_bytes(n, b, int(bool(general_sem)))
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
     rc = lib.pbn_binary_cluster(N.ptr(off_xyz), N.ptr(org_xyz), N.ptr(sem), N.ptr(seg_len), n, b, float(radius),
-                                int(min_pts), float(para_f), int(bool(nv_flag)), int(bool(general_sem)),
+                                int(min_pts), float(para_f), int(bool(nv_flag)), int(bool(general_sem)) | (2 if capacity else 0),
                                 N.ptr(cluster_id), N.ptr(cluster_num), N.ptr(den), N.ptr(centers), N.ptr(clt_sem),
                                 N.ptr(n_clusters), N.ptr(member_start), N.ptr(member_idx), N.ptr(ws), ws_bytes,
                                 N.current_stream())

@@ -199,3 +199,31 @@ def test_get_iou_matches_oracle():
                                                        torch.rand(int(offs[-1]), 1, device=DEV), 0)
     assert np.array_equal(iou2.cpu().numpy().view(np.int32), want.view(np.int32))
     assert set(np.unique(mask_label.cpu().numpy())) <= {-1.0, 0.0, 1.0}
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[8:-4] for p in GOLDEN])
+def test_capacity_mode_equals_exact_mode(path):
+    """pbn_binary_cluster with n_points as a CAPACITY (flags bit 1: the number of points that exist is sum(seg_len), a
+    device-side count -- the capacity-planned forward never reads it back): rows beyond the count hold garbage and must
+    neither be read nor change any output of the rows that exist."""
+    g = dict(np.load(path))
+    n = g["off"].shape[0]
+    pad = n // 3 + 100
+    rng = np.random.default_rng(1)
+    junk3 = rng.normal(0, 50, (pad, 3)).astype(np.float32)
+    junk3[::7] = np.nan
+    off = np.concatenate([g["off"], junk3]).astype(np.float32)
+    org = np.concatenate([g["org"], junk3[::-1]]).astype(np.float32)
+    sem = np.concatenate([g["sem"], np.full(pad, 77, np.int32)]).astype(np.int32)      # an invalid class id: must never be looked at
+    start = np.concatenate([[0], np.cumsum(g["seg"])])
+    general = any(len(np.unique(np.asarray(g["sem"])[a:b])) > 1 for a, b in zip(start[:-1], start[1:]))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    res = pbnet_ops.cluster_device(t(off), t(org), t(sem), t(g["seg"].astype(np.int32)), float(g["radius"]), int(g["min_pts"]),
+                                   nv_flag=bool(g["nv_flag"]), general_sem=general, capacity=True)
+    c = int(res.n_clusters.item())
+    assert c == g["center"].shape[0]
+    got = dict(cluster_id=res.cluster_id[:n].cpu().numpy(), cluster_num=res.cluster_num.cpu().numpy(),
+               den_queue=res.den[:n].cpu().numpy(), center=res.centers[:3 * c].cpu().numpy().reshape(c, 3),
+               clt_sem=res.clt_sem[:c].cpu().numpy(), member_start=res.member_start[:c + 1].cpu().numpy(),
+               member_idx=res.member_idx.cpu().numpy())
+    _assert_same(got, g)

