@@ -18,6 +18,8 @@ Results are bit-identical to the size-exact path whenever the same kernel config
 the true sizes); with slack the convolution tiles / pooling splits of a level may differ, which changes fp32 summation
 order only (tests/test_planned_gpu.py)."""
 import ctypes
+import os
+import sys
 from types import SimpleNamespace
 
 import numpy as np
@@ -33,6 +35,15 @@ OVF_NAMES = {1: "selected points", 2: "clusters", 4: "local-scene entries", 8: "
              16: "clusters of one (class, batch) segment", 32: "batch index outside [0, cluster_batch)", 64: "rows of a level"}
 MASK_THD = 0.45
 LOCAL_VOXEL = 0.02
+_DEBUG = os.environ.get("PBN_PLANNED_DEBUG", "0") == "1"
+
+
+def _dbg(stage, counts=None):
+    """PBN_PLANNED_DEBUG=1: synchronise after every stage and say where the forward is (hang / fault localisation)."""
+    if _DEBUG:
+        torch.cuda.synchronize()
+        sys.stderr.write("[planned] %s%s\n" % (stage, "" if counts is None else " counts=%s" % counts.tolist()[:8]))
+        sys.stderr.flush()
 
 
 class Capacities(object):
@@ -180,6 +191,7 @@ class PlannedForward(object):
         lin1 = _Lineage(coords1, n_vox, None, dev)
         feats1 = feat_voxel.contiguous()
         f = self._unet(m.MEUnet, lin1, cap.lv1, feats1, feats1.shape[1] * es)
+        _dbg("backbone done", counts)
         v2p = v2p_index.long()
         v2p_z = lin1.inv_perm[v2p]                                   # Z-order row of every point's voxel
         point_feat_p = f[v2p_z]
@@ -192,6 +204,7 @@ class PlannedForward(object):
         sem_pred, sem_prob, table, block_hist = stage_ops.sem_argmax_table(sem_score, batch_head.contiguous(), nb)
         out = {"sem_pred_p": sem_pred, "sem_pred_score_p": sem_score, "offset_pred_p": offset_p, "counts": counts}
 
+        _dbg("heads done", counts)
         # ---- class gate -> selection -> grouping (PBNet.py:151-179), sizes on the device ----
         n_cls = int(m.sem_num)
         n_seg = (n_cls - 2) * nb
@@ -203,6 +216,7 @@ class PlannedForward(object):
                                                                       int(cap.points))
         res = pbnet_ops.cluster_device(ins_off, ins_orig, ins_sem, seg_len, m.radius, m.min_pts, capacity=True)
 
+        _dbg("grouping done", counts)
         # ---- local scenes (PBNet.py:182-234): plan on the device, rows by one launch ----
         c_cap, e_cap, r_cap = int(cap.clusters), int(cap.entries), int(cap.rows)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -230,11 +244,13 @@ class PlannedForward(object):
             vp(sem_prob2.data_ptr()), sem_prob2.stride(0), None, _DT[dt], N.ptr(point_idx), N.ptr(row_scene), N.ptr(coords2),
             vp(feat2.data_ptr()), ld2, st()), "pbn_local_scene_rows_dev")
 
+        _dbg("local scene rows done", counts)
         # ---- mask branch (PBNet.py:236-252) ----
         lin2 = _Lineage(coords2, r_cap, cnt(CNT.ROWS), dev)
         f2 = self._unet(m.D_Unet, lin2, cap.lv2, feat2, ld2 * es)
         mask_score = self._mlp(m.linear_binary, f2, lin2.inverse, lin2.inv_perm, r_cap, cnt(CNT.ROWS))      # [r_cap, 1]
 
+        _dbg("mask branch done", counts)
         # ---- proposals (PBNet.py:317-347) ----
         per_scene = torch.empty(c_cap, **i32)
         block_cnt = torch.empty(max(int(lib.pbn_select_blocks(r_cap)), 1), **i32)
@@ -255,6 +271,7 @@ class PlannedForward(object):
             vp(point_feat_p.data_ptr()), point_feat_p.stride(0), c_in, _DT[dt], N.ptr(prop_idx), vp(prop_ms.data_ptr()),
             N.ptr(coords3), vp(feat3.data_ptr()), st()), "pbn_proposal_rows_dev")
 
+        _dbg("proposals done", counts)
         # ---- score branch (PBNet.py:255-279) ----
         lin3 = _Lineage(coords3, r_cap, cnt(CNT.PROPOSAL_ROWS), dev)
         f3 = self._unet(m.score_Unet, lin3, cap.lv3, feat3, c_in * es)
@@ -272,6 +289,7 @@ class PlannedForward(object):
                                      N.ptr(mx), N.ptr(av), vp(pw.data_ptr()), pws, st()), "pbn_segment_pool")
         pooled = (mx + av).to(dt)
         clt_scores = stage_ops.mlp_rows(m.linear_IOU, pooled).view(-1)
+        _dbg("score branch done", counts)
         # a level of one of the three pyramids that outgrew its capacity (rows were dropped): flag it
         ovf = torch.stack(self._level_overflow).any().to(torch.int32) * 64
         counts[CNT.OVERFLOW:CNT.OVERFLOW + 1] |= ovf

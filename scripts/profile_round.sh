@@ -1,0 +1,31 @@
+#!/bin/bash
+# Everything profiles/ holds for one milestone, from one box:  bash scripts/profile_round.sh r02_a
+#   <tag>_bench.json                   the default bench.py line
+#   <tag>_bench_kernel_stats.csv       rocprofv3 --kernel-trace --stats of the same command (no CPU baseline)
+#   <tag>_inflight1_kernel_stats.csv   the same with one scene in flight
+#   <tag>_pmc_summary.json             HBM traffic per kernel family: two --pmc passes (FETCH_SIZE, WRITE_SIZE), own runs
+#   <tag>_sq_conv_summary.json         SQ counters (MFMA busy, waits) of the convolution kernels, own pass
+R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT unset)}
+TAG=${1:?usage: profile_round.sh <tag>}
+# bench.py sets this with os.environ.setdefault, but under rocprofv3 the profiler has initialised the runtime before Python
+# starts: export it in the shell so that the profiled runs use the same 8 hardware queues as the plain run
+export GPU_MAX_HW_QUEUES=8
+cd /tmp && export TMPDIR=/tmp
+cd $R
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+timeout 600 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err; tail -1 $O/${TAG}_bench.json | cut -c1-200
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --no-extras > $O/kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-extras --inflight 1 > $O/kt1.log 2>&1
+cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv
+cp $(find $O/kt1 -name "*kernel_stats.csv" | head -1) $O/${TAG}_inflight1_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  d=/tmp/pmc_$c
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d $d -o bench -- python bench.py --no-extras --steps 5 --warmup 2 --repeats 1 > $O/pmc_$c.log 2>&1
+  mkdir -p /tmp/pmc_flat_$c && cp $(find $d -name "bench_counter_collection.csv" | head -1) /tmp/pmc_flat_$c/bench_counter_collection.csv
+done
+python scripts/summarize_pmc.py /tmp/pmc_flat_FETCH_SIZE /tmp/pmc_flat_WRITE_SIZE $O/${TAG}_pmc_summary.json > $O/pmc_summary.log 2>&1; tail -3 $O/pmc_summary.log
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_sq -o sq -- python bench.py --no-extras --inflight 1 --steps 5 --warmup 2 --repeats 1 > $O/pmc_sq.log 2>&1
+python scripts/summarize_sq.py $(find /tmp/pmc_sq -name "sq_counter_collection.csv" | head -1) $(find /tmp/pmc_sq -name "sq_kernel_trace.csv" | head -1) $O/${TAG}_sq_conv_summary.json > $O/sq_summary.log 2>&1; tail -12 $O/sq_summary.log
+find $O -name "*_kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; rm -rf $O/kt $O/kt1
+ls $O

@@ -16,7 +16,7 @@ import sys
 def family(name):
     if "k_spconv_reduce" in name:
         return "k_spconv_reduce"
-    if "k_spconv<" in name:
+    if "k_spconv<" in name or "k_spconv_wave<" in name:      # both convolution kernel families
         return "k_spconv"
     if "pbn::" in name:
         return "pbn_other"
@@ -36,7 +36,7 @@ def load(d):
 def main():
     fetch, write, out = sys.argv[1:4]
     f, w = load(fetch), load(write)
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python bench.py --no-cpu-baseline --steps 5 --warmup 2",
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python bench.py --no-extras --steps 5 --warmup 2 --repeats 1",
            "units": "bytes per launch; FETCH_SIZE x2 (gfx950 wide-load correction), WRITE_SIZE as reported, both x1024 (KB)",
            "families": {}}
     for k in sorted(set(f) | set(w)):
@@ -44,7 +44,13 @@ def main():
         wb = 1024.0 * w[k][1] / max(w[k][0], 1)
         res["families"][k] = {"launches": f[k][0], "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                               "traffic_bytes_per_launch": round(fb + wb)}
-    res["k_spconv_traffic_bytes_per_launch"] = res["families"]["k_spconv"]["traffic_bytes_per_launch"]
+    conv = res["families"]["k_spconv"]
+    res["k_spconv_traffic_bytes_per_launch"] = conv["traffic_bytes_per_launch"]
+    red = res["families"].get("k_spconv_reduce")
+    # per convolution OP: its own launch + its share of the split-K reduce launches
+    extra = red["traffic_bytes_per_launch"] * red["launches"] / max(conv["launches"], 1) if red else 0
+    res["reduce_launches_per_conv_launch"] = round(red["launches"] / max(conv["launches"], 1), 4) if red else 0.0
+    res["traffic_bytes_per_conv_op_incl_reduce"] = round(conv["traffic_bytes_per_launch"] + extra)
     with open(out, "w") as fo:
         json.dump(res, fo, indent=1)
     print(json.dumps(res["families"], indent=1))

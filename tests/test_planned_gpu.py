@@ -176,8 +176,11 @@ def test_bench_scene_planned_bf16():
             fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
+    pf.capture(*_args(b), teacher=t)
+    rep = pf.finish(pf.replay())
+    for a_, w_ in zip(rep["proposals"], got["proposals"]):
+        assert torch.equal(a_, w_)
+    t_graph = timed(lambda: pf.finish(pf.replay()))
     t_eager = timed(lambda: _eager(model, b, t))
     t_plan = timed(lambda: pf(*_args(b), teacher=t))
-    pf.capture(*_args(b), teacher=t)
-    t_graph = timed(lambda: pf.finish(pf.replay()))
     print("bench scene, one in flight: size-exact %.3f ms, planned %.3f ms, planned + HIP graph %.3f ms" % (t_eager, t_plan, t_graph))
