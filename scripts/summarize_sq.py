@@ -6,9 +6,12 @@ import collections, csv, json, sys
 
 cc, kt, out = sys.argv[1:4]
 dur = {}
-with open(kt) as f:
-    for r in csv.DictReader(f):
-        dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3     # us
+try:
+    with open(kt) as f:
+        for r in csv.DictReader(f):
+            dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3     # us
+except OSError:
+    pass        # the counter file carries the timestamps of every dispatch as well
 
 
 def group(name, grid):
@@ -30,7 +33,7 @@ with open(cc) as f:
         a = agg[g]
         if r["Dispatch_Id"] not in a["launches"]:
             a["launches"].add(r["Dispatch_Id"])
-            a["us"] += dur.get(r["Dispatch_Id"], 0.0)
+            a["us"] += dur.get(r["Dispatch_Id"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
         a["c"][r["Counter_Name"]] += float(r["Counter_Value"])
 res = {"source": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES "
                  "(own pass) -- python bench.py --no-extras --inflight 1 --steps 5 --warmup 2 --repeats 1",
