@@ -62,16 +62,15 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     const int K = a.K;
     const int KS = K | 1;  // odd row pitch: conflict-free column reads of the rulebook tile
     const int cg = a.cg;
-    const int n_groups = (a.n_steps + cg - 1) / cg;                                 // upper bound (every step populated)
+    const int n_groups = a.n_steps / cg;
     constexpr int DEPTH = RING - 1;                                                 // weight tiles in flight ahead
-    const int list_cap = a.n_steps + (DEPTH + 2) * CGMAX;                           // step list incl. the trailing null steps
     u32x4* s_w = reinterpret_cast<u32x4*>(smem);                                    // RING slots x cg * NT * 64 vectors
     int* s_nbr = reinterpret_cast<int*>(smem + (size_t)RING * cg * NT * 1024);      // TM * KS
     int* s_valid = s_nbr + TM * KS;                                                 // K fragment masks
-    int* s_step = s_valid + ((K + 3) & ~3);                                         // list_cap step descriptors (populated steps, in order)
-    int* s_smask = s_step + list_cap;                                               // list_cap fragment masks of those steps (+ [list_cap]: count)
-    int* s_masks = s_smask + list_cap + 4;                                          // n_groups + 4 fragment masks per group
-    float* s_ss = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(s_masks + n_groups + 4) + 15) & ~(uintptr_t)15);  // scale | shift
+    int* s_grp = s_valid + ((K + 3) & ~3);                                          // n_groups + 4 (entry n_groups = count)
+    int* s_masks = s_grp + n_groups + 4;                                            // n_groups + 4 fragment masks
+    int* s_gko = s_masks + n_groups + 4;                                            // n_groups + 4: offset | sub-group << 16
+    float* s_ss = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(s_gko + n_groups + 4) + 15) & ~(uintptr_t)15);  // scale | shift
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform for the compiler
@@ -119,28 +118,22 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
         if (any) atomicOr(&s_valid[k], 1 << fr);
     }
     __syncthreads();
-    // Ordered list of the POPULATED steps (a step = 4 consecutive 16-byte vectors of the flattened (offset, channel) axis) with
-    // their fragment masks; a barrier GROUP is cg consecutive entries of this list, whatever offsets they belong to, so a
-    // narrow layer (32 / 64 channels: 1 / 2 steps per offset) pays one barrier + one weight DMA per 4 steps instead of per
-    // offset.  Descriptor: step | offset of lane group 0 << 16 | step within its offset << 24; null step: offset 255.
+    // ordered list of the groups that touch at least one populated offset, with their fragment masks (wave 0)
     const int vpo = a.vpo;
     const bool wide = (vpo & 3) == 0;
-    const int spo = wide ? (vpo >> 2) : 1;               // steps per offset (wide layers)
-    constexpr int NULL_STEP = 255 << 16;                 // step 0's weights (finite), no neighbour: adds zeros
+    const int gpo = wide ? (vpo >> 2) / cg : 1;          // groups per offset (wide layers)
     if (wave == 0) {
         int base = 0;
-        for (int s0 = 0; s0 < a.n_steps; s0 += 64) {
-            const int st = s0 + lane;
-            int fm = 0, ko = 0, sub = 0;
-            if (st < a.n_steps) {
+        for (int g0 = 0; g0 < n_groups; g0 += 64) {
+            const int gi = g0 + lane;
+            int fm = 0, ko = 0;
+            if (gi < n_groups) {
                 if (wide) {
-                    ko = st / spo;
-                    sub = st - ko * spo;
+                    ko = gi / gpo;
                     fm = s_valid[ko];
                 } else {
-                    ko = (st * 4) / vpo;
                     for (int q = 0; q < 4; ++q) {
-                        const int kq = (st * 4 + q) / vpo;
+                        const int kq = (gi * 4 + q) / vpo;
                         if (kq < K) fm |= s_valid[kq];
                     }
                 }
@@ -149,27 +142,16 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
             const unsigned long long m = __ballot(ok);
             if (ok) {
                 const int pos = base + __popcll(m & ((1ULL << lane) - 1ULL));
-                s_step[pos] = st | (ko << 16) | (sub << 24);
-                s_smask[pos] = fm | ((a.dbg & 1) ? 0xffff : 0);
+                s_grp[pos] = gi;
+                s_masks[pos] = fm | ((a.dbg & 1) ? 0xffff : 0);
+                s_gko[pos] = ko | ((gi - ko * gpo) << 16);
             }
             base += __popcll(m);
         }
-        const int ngw = (base + cg - 1) / cg;
-        for (int e = base + lane; e < (ngw + DEPTH + 1) * cg && e < list_cap; e += 64) { s_step[e] = NULL_STEP; s_smask[e] = 0; }
-        if (lane == 0) s_smask[list_cap] = ngw;
-        __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave reads its own LDS writes back below
-        __builtin_amdgcn_wave_barrier();
-        for (int gp = lane; gp < ngw + 4 && gp < n_groups + 4; gp += 64) {
-            int fm = 0;
-            for (int c = 0; c < cg; ++c) {
-                const int e = gp * cg + c;
-                if (e < (ngw + DEPTH + 1) * cg && e < list_cap) fm |= s_smask[e];
-            }
-            s_masks[gp] = fm;
-        }
+        if (lane == 0) s_grp[n_groups] = base;
     }
     __syncthreads();
-    int ng = __builtin_amdgcn_readfirstlane(s_smask[list_cap]);
+    int ng = __builtin_amdgcn_readfirstlane(s_grp[n_groups]);
     int g_lo = 0;
     if (a.ksplit > 1) {  // this workgroup reduces only its slice of the group list
         g_lo = (int)((long long)ng * blockIdx.z / a.ksplit);
@@ -203,22 +185,17 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
 
     // gather byte offsets of group-list entry POS (all out of range when MORE is false): every chunk of a group reads
     // the same neighbour row, +64 B per chunk
-#define PBN_GROUP_ROWS(POS, MORE, VOFF, CG)                                                                           \
+#define PBN_GROUP_ROWS(POS, GI, MORE, VOFF, CG)                                                                       \
     {                                                                                                                 \
-        _Pragma("unroll") for (int c_ = 0; c_ < (CG); ++c_) {                                                         \
-            const int d_ = __builtin_amdgcn_readfirstlane(s_step[(POS) * (CG) + c_]);                                 \
-            int ko_, cv_;                                                                                             \
-            if (wide) { ko_ = (d_ >> 16) & 0xff; cv_ = ((d_ >> 24) & 0xff) * 4 + g; }                                 \
-            else {                                                                                                    \
-                const int v_ = (d_ & 0xffff) * 4 + g;                                                                 \
-                ko_ = ((d_ >> 16) & 0xff) == 255 ? 255 : (v_ >> vshift);                                              \
-                cv_ = v_ & (vpo - 1);                                                                                 \
-            }                                                                                                         \
-            _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                          \
-                const int r_ = wave * RW + f * 16 + rl;                                                               \
-                const int src_ = ((MORE) && ko_ < K) ? s_nbr[r_ * KS + ko_] : -1;                                     \
-                VOFF[c_][f] = (src_ >= 0 && !(a.dbg & 4)) ? (unsigned)src_ * ld_bytes + (unsigned)cv_ * 16u : OOB;    \
-            }                                                                                                         \
+        int ko_, cv_;                                                                                                 \
+        if (wide) {                                                                                                   \
+            const int pk_ = __builtin_amdgcn_readfirstlane(s_gko[POS]);                                               \
+            ko_ = pk_ & 0xffff; cv_ = (pk_ >> 16) * (CG) * 4 + g;                                                     \
+        } else { const int v_ = (GI) * 4 + g; ko_ = v_ >> vshift; cv_ = v_ & (vpo - 1); }                             \
+        _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                              \
+            const int r_ = wave * RW + f * 16 + rl;                                                                   \
+            const int src_ = ((MORE) && ko_ < K) ? s_nbr[r_ * KS + ko_] : -1;                                         \
+            VOFF[f] = (src_ >= 0 && !(a.dbg & 4)) ? (unsigned)src_ * ld_bytes + (unsigned)cv_ * 16u : OOB;            \
         }                                                                                                             \
     }
     // refill chunk C's operand registers in place ("+v": the load lands in the register the MFMAs just read)
@@ -226,7 +203,7 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     {                                                                                                                 \
         _Pragma("unroll") for (int f = 0; f < NF; ++f)                                                                \
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen"                                                   \
-                         : "+v"(x[C][f]) : "v"(VOFF[C][f]), "s"(rs_in), "s"(0));                                      \
+                         : "+v"(x[C][f]) : "v"(VOFF[f]), "s"(rs_in), "s"((C) * 64));                                  \
     }
     // wait until at most N vector-memory loads are outstanding; names chunk C's registers so that their readers
     // are ordered behind the wait
@@ -238,19 +215,19 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     // weight tile of group GI -> ring slot at LDS byte address SLOT: piece p = wave + 4 i is step p / NT, channel tile
     // p % NT; every wave issues the same number of pieces (the tail is clamped onto the last piece: a benign duplicate
     // copy).  MORE false (past the last group): the same instructions with an out-of-range offset: no memory traffic.
-#define PBN_DMA_W(POS, MORE, SLOT, CG)                                                                                \
+#define PBN_DMA_W(GI, MORE, SLOT, CG)                                                                                 \
     {                                                                                                                 \
+        const unsigned gbase_ = ((unsigned)(GI) * (CG) * a.ntiles_total + tile0) * 1024u;                             \
         const unsigned wv_ = ((MORE) && !(a.dbg & 8)) ? w_lane : OOB;                                                 \
         _Pragma("unroll") for (int i = 0; i < ((CG) * NT + 3) / 4; ++i) {                                             \
             const int p_ = min(wave + 4 * i, (CG) * NT - 1);                                                          \
             const int c_ = p_ / NT, t_ = p_ - c_ * NT;                                                                \
-            const unsigned st_ = (unsigned)__builtin_amdgcn_readfirstlane(s_step[(POS) * (CG) + c_]) & 0xffffu;       \
             unsigned keep_;                                                                                           \
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"                                        \
                          "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"                               \
                          : "=&s"(keep_)                                                                               \
                          : "s"(__builtin_amdgcn_readfirstlane((SLOT) + (unsigned)p_ * 1024u)), "v"(wv_), "s"(rs_w),   \
-                           "s"(__builtin_amdgcn_readfirstlane(st_ * w_step_bytes + (unsigned)(tile0 + t_) * 1024u))   \
+                           "s"(__builtin_amdgcn_readfirstlane(gbase_ + c_ * w_step_bytes + t_ * 1024u))               \
                          : "memory");                                                                                 \
         }                                                                                                             \
     }
@@ -270,12 +247,14 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
         const u32x4* cur_ = s_w + slot * ((CG) * NT * 64);                                                            \
         const unsigned free_ = slot == 0 ? RING - 1 : slot - 1;   /* slot of group POS-1 = slot of group POS+DEPTH */  \
         slot = slot == RING - 1 ? 0 : slot + 1;                                                                       \
-        unsigned vnext_[CG][NF];                                                                                      \
+        unsigned vnext_[NF];                                                                                          \
         {                                                                                                             \
-            PBN_DMA_W((POS) + DEPTH, (POS) + DEPTH < ng, lds_w + free_ * slot_bytes, CG);                             \
+            const int gdma_ = __builtin_amdgcn_readfirstlane(s_grp[(POS) + DEPTH]);                                   \
+            PBN_DMA_W(gdma_, (POS) + DEPTH < ng, lds_w + free_ * slot_bytes, CG);                                     \
+            const int gnext_ = __builtin_amdgcn_readfirstlane(s_grp[(POS) + 1]);                                      \
             const unsigned fnext_ = (unsigned)__builtin_amdgcn_readfirstlane(s_masks[(POS) + 1]);                     \
             fcur = more_ ? fnext_ : 0u;                                                                               \
-            PBN_GROUP_ROWS((POS) + 1, more_, vnext_, CG);                                                             \
+            PBN_GROUP_ROWS((POS) + 1, gnext_, more_, vnext_, CG);                                                     \
         }                                                                                                             \
         /* the asm statements that define x[][] stay on the straight-line path: inside a branch the compiler would */ \
         /* merge them through register copies, i.e. read registers whose loads are still in flight                 */ \
@@ -302,9 +281,11 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
         unsigned fcur = (unsigned)__builtin_amdgcn_readfirstlane(s_masks[g_lo]);                                      \
         unsigned slot = 0;                                                                                            \
         _Pragma("unroll") for (int j = 0; j < DEPTH; ++j) {                                                           \
-            unsigned v0_[CG][NF];                                                                                     \
-            PBN_DMA_W(g_lo + j, g_lo + j < ng, lds_w + (unsigned)j * slot_bytes, CG);                                 \
-            PBN_GROUP_ROWS(g_lo, j == DEPTH - 1, v0_, CG);                                                            \
+            const int gj_ = __builtin_amdgcn_readfirstlane(s_grp[g_lo + j]);                                          \
+            unsigned v0_[NF];                                                                                         \
+            PBN_DMA_W(gj_, g_lo + j < ng, lds_w + (unsigned)j * slot_bytes, CG);                                      \
+            const int g0_ = __builtin_amdgcn_readfirstlane(s_grp[g_lo]);                                              \
+            PBN_GROUP_ROWS(g_lo, g0_, j == DEPTH - 1, v0_, CG);                                                       \
             _Pragma("unroll") for (int c = 0; c < (CG); ++c) { PBN_LOAD_X(v0_, c); }                                  \
         }                                                                                                             \
         for (int pos = g_lo; pos < ng; ++pos) PBN_GROUP(pos, CG);                                                     \
@@ -411,14 +392,16 @@ template <typename T, int NF, int NT, int RING>
 int launch_ring(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes, hipStream_t stream) {
     constexpr int TM = 64 * NF;
     const int KS = a.K | 1;
-    // steps per barrier group: 4 consecutive POPULATED steps whatever offsets they belong to; 3 when an offset is 3 or 6
-    // steps wide (96 / 192 channels: a group is then one offset / half an offset and the 4-chunk register set is avoided)
-    a.cg = a.n_steps < CGMAX ? a.n_steps : CGMAX;
-    if ((a.vpo & 3) == 0 && ((a.vpo >> 2) % 3) == 0 && ((a.vpo >> 2) % 4) != 0 && a.n_steps >= 3) a.cg = 3;
-    const int n_groups = (a.n_steps + a.cg - 1) / a.cg;
-    const size_t list_cap = (size_t)a.n_steps + (size_t)(RING + 1) * CGMAX;
+    // steps per barrier group: the largest divisor <= 4 of the steps per offset (1 when offsets are narrower than a step)
+    a.cg = 1;
+    if ((a.vpo & 3) == 0) {
+        const int spo = a.vpo >> 2;
+        for (int c = CGMAX; c >= 1; --c)
+            if (spo % c == 0) { a.cg = c; break; }
+    }
+    const int n_groups = a.n_steps / a.cg;
     const size_t lds = (size_t)RING * a.cg * NT * 1024 +
-                       sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 2 * list_cap + 4 + ((size_t)n_groups + 4) + 2 * NT * 16 + 4);
+                       sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 3 * ((size_t)n_groups + 4) + 2 * NT * 16 + 4);
     if (lds > 160 * 1024) return PBN_ERR_UNSUPPORTED;
     auto kern = k_spconv<T, NF, NT, RING>;
     if (lds > 64 * 1024)

@@ -19,3 +19,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _hang_watchdog(request):
+    """A GPU test that hangs inside a native call cannot be interrupted by pytest-timeout (signals are not delivered while
+    the interpreter sits in C): a watchdog thread dumps every Python stack and ends the process instead, so a hang costs
+    minutes of GPU budget, not the whole call, and says where it is."""
+    import faulthandler
+    if request.node.get_closest_marker("gpu") is not None:
+        faulthandler.dump_traceback_later(240, exit=True)
+        yield
+        faulthandler.cancel_dump_traceback_later()
+    else:
+        yield

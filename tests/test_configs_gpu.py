@@ -213,7 +213,9 @@ def test_c3_bf16_training_step_at_scene_size_vs_fp32():
         by_net[r[0].split(".")[0]].append(r[1])
     for k, v in sorted(by_net.items()):
         print("  %-16s %3d tensors: cosine min %.4f median %.4f" % (k, len(v), min(v), float(np.median(v))))
-    near = [r for r in rows if r[0].startswith(("linear_binary.", "D_Unet.block8.", "D_Unet.final_sematic.", "linear_IOU.3."))]
+    # (gradients that are zero in exact arithmetic -- a bias in front of a train-mode BatchNorm -- are rounding noise: skipped)
+    near = [r for r in rows if r[0].startswith(("linear_binary.", "D_Unet.block8.", "D_Unet.final_sematic.", "linear_IOU.3."))
+            and r[3] > 1e-6]
     assert len(near) >= 10
     bad = [r for r in near if not (r[1] >= 0.98 and 0.9 <= r[2] <= 1.1)]
     assert not bad, bad
