@@ -28,8 +28,13 @@ def _hang_watchdog(request):
     minutes of GPU budget, not the whole call, and says where it is."""
     import faulthandler
     if request.node.get_closest_marker("gpu") is not None:
-        faulthandler.dump_traceback_later(240, exit=True)
+        log = open(os.path.join(ROOT, "gpurun_out", "hang_watchdog.log") if os.path.isdir(os.path.join(ROOT, "gpurun_out"))
+                   else os.devnull, "a")
+        log.write("== %s\n" % request.node.nodeid)
+        log.flush()
+        faulthandler.dump_traceback_later(240, exit=True, file=log)       # pytest captures stderr: write to a file instead
         yield
         faulthandler.cancel_dump_traceback_later()
+        log.close()
     else:
         yield

@@ -152,8 +152,7 @@ def test_whole_forward_in_a_hip_graph_fp16(model):
 
 
 def test_bench_scene_planned_bf16():
-    """The benchmarked configuration: planned forward == size-exact forward (integer outputs), and what it buys."""
-    import time
+    """The benchmarked configuration: planned forward == size-exact forward (integer outputs); whole forward from a graph."""
     cfg = get_config(test=True)
     torch.manual_seed(22)
     model = PBNet(cfg).to(DEV).eval()
@@ -167,20 +166,11 @@ def test_bench_scene_planned_bf16():
     got = pf(*_args(b), teacher=t)
     _same_proposals(got, want, 2e-2)
 
-    def timed(fn, n=20):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n * 1e3
     pf.capture(*_args(b), teacher=t)
-    rep = pf.finish(pf.replay())
-    for a_, w_ in zip(rep["proposals"], got["proposals"]):
-        assert torch.equal(a_, w_)
-    t_graph = timed(lambda: pf.finish(pf.replay()))
-    t_eager = timed(lambda: _eager(model, b, t))
-    t_plan = timed(lambda: pf(*_args(b), teacher=t))
-    print("bench scene, one in flight: size-exact %.3f ms, planned %.3f ms, planned + HIP graph %.3f ms" % (t_eager, t_plan, t_graph))
+    for _ in range(2):
+        rep = pf.finish(pf.replay())
+        torch.cuda.synchronize()
+        for a_, w_ in zip(rep["proposals"], got["proposals"]):
+            assert torch.equal(a_, w_)
+        assert torch.equal(rep["clt_scores"], got["clt_scores"])
+    # timings of the three forms live in scripts/debug_planned.py / scripts/debug_inflight_graph.py
