@@ -121,12 +121,10 @@ int pbn_coords_stride(const int32_t* fine_coords, const int32_t* n_fine_dev, int
                       size_t workspace_bytes, pbn_stream_t stream);
 
 /* Output-stationary kernel map: nbr[row, k] = row of (out_coords[row] + offsets[k]) in the table, or -1.
- * offsets int32[n_offsets,3] (already multiplied by the tensor stride).  table_stride = tensor stride of the level the
- * table was built for (pbn_coords_unique: 1; pbn_coords_stride: its stride_out): the table's slot function keeps the
- * cells of a 4x4x4 block of that level in one run of 64 slots, so that the probes of a row stay in a few cache lines. */
+ * offsets int32[n_offsets,3] (already multiplied by the tensor stride). */
 int pbn_kernel_map(const int32_t* out_coords, const int32_t* n_out_dev, int n_out_max, const int32_t* offsets,
-                   int n_offsets, int table_stride, const uint64_t* table_keys, const int32_t* table_vals, int capacity,
-                   int32_t* nbr, pbn_stream_t stream);
+                   int n_offsets, const uint64_t* table_keys, const int32_t* table_vals, int capacity, int32_t* nbr,
+                   pbn_stream_t stream);
 
 /* Kernel map of a K^3 hyper-cube whose offsets are generated on the fly: odd K centred, even K not, offsets scaled by
  * tensor_stride, first spatial dimension fastest when x_fastest != 0 (the MinkowskiEngine convention assumed here). */

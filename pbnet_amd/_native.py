@@ -68,7 +68,7 @@ SIGNATURES = {
                                   c_size, c_vp]),
     "pbn_coords_stride": (c_int, [c_i32p, c_i32p, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_i32p, c_i32p, c_i32p,
                                   c_i32p, c_vp, c_size, c_vp]),
-    "pbn_kernel_map": (c_int, [c_i32p, c_i32p, c_int, c_i32p, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
+    "pbn_kernel_map": (c_int, [c_i32p, c_i32p, c_int, c_i32p, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_up_table": (c_int, [c_i32p, c_i32p, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_spconv_forward": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_i32p, c_int, c_vp, c_int, c_int, c_int,
                                    c_f32p, c_f32p, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp]),

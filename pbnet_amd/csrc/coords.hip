@@ -11,7 +11,6 @@
 // capacity = pow2 >= 2n.  Values: smallest inserting row (atomicMin) => deterministic "first occurrence".
 // Row counts that depend on the data stay on the DEVICE (n_out pointers); kernels take an upper bound for the grid
 // and read the real count, so a whole coordinate pyramid is built without a host round trip.
-#include <cstdlib>
 #include "pbn_common.h"
 
 namespace pbn {
@@ -34,24 +33,9 @@ __device__ __forceinline__ int floor_div(int a, int s) {  // s > 0
     return (a % s != 0 && a < 0) ? q - 1 : q;
 }
 
-// Slot of a key in a level's table.  Locality-preserving: the 4 x 4 x 4 block of level cells a coordinate lies in picks a
-// run of 64 consecutive slots (hash of the block), the cell inside the block picks the slot of the run.  A kernel-map row
-// probes 27 / 125 neighbouring cells: with a scattering hash those are 27 / 125 random 64-byte lines of the table; here
-// they fall into the runs of <= 8 blocks that Z-order neighbours share (linear probing resolves overlapping runs).
-// shift = log2(tensor stride of the level): cell index bits sit at [shift, shift + 2) of every coordinate.
-// shift < 0: plain scattering hash (PBN_HASH_LOCAL=0, kept for A/B).
-__device__ __forceinline__ unsigned table_slot(unsigned long long key, int shift, unsigned mask) {
-    if (shift < 0) return hash64(key) & mask;
-    const unsigned x = (unsigned)(key >> 32) & 0xffffu, y = (unsigned)(key >> 16) & 0xffffu, z = (unsigned)key & 0xffffu;
-    const unsigned cell = ((x >> shift) & 3u) | (((y >> shift) & 3u) << 2) | (((z >> shift) & 3u) << 4);
-    const unsigned long long lowbits = (unsigned long long)(3u << shift);
-    const unsigned long long block = key & ~((lowbits << 32) | (lowbits << 16) | lowbits);
-    return ((hash64(block) << 6) | cell) & mask;
-}
-
 __device__ __forceinline__ int table_insert_min(unsigned long long* __restrict__ keys, int* __restrict__ vals,
-                                                unsigned mask, unsigned long long key, int row, int shift) {
-    unsigned h = table_slot(key, shift, mask);
+                                                unsigned mask, unsigned long long key, int row) {
+    unsigned h = hash64(key) & mask;
     while (true) {
         unsigned long long prev = atomicCAS(&keys[h], EMPTY_KEY, key);
         if (prev == EMPTY_KEY || prev == key) break;
@@ -62,23 +46,14 @@ __device__ __forceinline__ int table_insert_min(unsigned long long* __restrict__
 }
 
 __device__ __forceinline__ int table_find(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
-                                          unsigned mask, unsigned long long key, int shift) {
-    unsigned h = table_slot(key, shift, mask);
+                                          unsigned mask, unsigned long long key) {
+    unsigned h = hash64(key) & mask;
     while (true) {
         const unsigned long long k = keys[h];
         if (k == key) return vals[h];
         if (k == EMPTY_KEY) return -1;
         h = (h + 1) & mask;
     }
-}
-
-// host: log2 of a level's tensor stride, or -1 when the locality-preserving slot function is switched off (PBN_HASH_LOCAL=0)
-static inline int table_shift(int stride) {
-    static const int local = getenv("PBN_HASH_LOCAL") ? atoi(getenv("PBN_HASH_LOCAL")) : 1;
-    if (!local) return -1;
-    int s = 0;
-    while ((1 << (s + 1)) <= stride && s < 13) ++s;
-    return s;
 }
 
 __device__ __forceinline__ int real_n(const int* n_dev, int n_max) {
@@ -90,13 +65,12 @@ __device__ __forceinline__ int real_n(const int* n_dev, int n_max) {
 // ---- unique ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void k_insert_rows(const int* __restrict__ coords, const int* n_dev, int n_max,
                                                     unsigned long long* __restrict__ keys, int* __restrict__ vals,
-                                                    unsigned mask, int shift, int* __restrict__ slot_of_row,
-                                                    int* __restrict__ status) {
+                                                    unsigned mask, int* __restrict__ slot_of_row, int* __restrict__ status) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= real_n(n_dev, n_max)) return;
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
     if (!in_range(c.x, c.y, c.z, c.w)) atomicOr(status, 1);
-    slot_of_row[i] = table_insert_min(keys, vals, mask, pack4(c.x, c.y, c.z, c.w), i, shift);
+    slot_of_row[i] = table_insert_min(keys, vals, mask, pack4(c.x, c.y, c.z, c.w), i);
 }
 
 // "row i is the first occurrence of its key": the slot's value is the smallest inserting row
@@ -213,14 +187,14 @@ __global__ __launch_bounds__(TPB) void k_unique_write(const int* __restrict__ co
 // ---- stride: parent coordinate of every fine row ------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void k_insert_parents(const int* __restrict__ coords, const int* n_dev, int n_max,
                                                        int stride_out, unsigned long long* __restrict__ keys,
-                                                       int* __restrict__ vals, unsigned mask, int shift,
+                                                       int* __restrict__ vals, unsigned mask,
                                                        int* __restrict__ slot_of_row) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= real_n(n_dev, n_max)) return;
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
     const int px = floor_div(c.y, stride_out) * stride_out, py = floor_div(c.z, stride_out) * stride_out,
               pz = floor_div(c.w, stride_out) * stride_out;
-    slot_of_row[i] = table_insert_min(keys, vals, mask, pack4(c.x, px, py, pz), i, shift);
+    slot_of_row[i] = table_insert_min(keys, vals, mask, pack4(c.x, px, py, pz), i);
 }
 
 // coarse coords (first-occurrence order), child -> (parent row, k), 8-way child table of the k=2,s=2 convolution,
@@ -261,7 +235,7 @@ __global__ __launch_bounds__(TPB) void k_stride_write(const int* __restrict__ co
 __global__ __launch_bounds__(TPB) void k_kernel_map(const int* __restrict__ out_coords, const int* n_dev, int n_max,
                                                    const int* __restrict__ offsets, int K,
                                                    const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
-                                                   unsigned mask, int shift, int* __restrict__ nbr) {
+                                                   unsigned mask, int* __restrict__ nbr) {
     const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
     const int n = real_n(n_dev, n_max);
     if (e >= (long long)n * K) return;
@@ -269,7 +243,7 @@ __global__ __launch_bounds__(TPB) void k_kernel_map(const int* __restrict__ out_
     const int4 c = reinterpret_cast<const int4*>(out_coords)[row];
     const int x = c.y + offsets[3 * k + 0], y = c.z + offsets[3 * k + 1], z = c.w + offsets[3 * k + 2];
     int r = -1;
-    if (in_range(c.x, x, y, z)) r = table_find(keys, vals, mask, pack4(c.x, x, y, z), shift);
+    if (in_range(c.x, x, y, z)) r = table_find(keys, vals, mask, pack4(c.x, x, y, z));
     nbr[e] = r;
 }
 
@@ -343,7 +317,7 @@ int coords_unique_impl(const int32_t* coords, const int32_t* n_dev, int n_max, u
     const int nb = cdiv(n_max, TPB), nsb = cdiv(n_max, SCAN_TILE);
     const unsigned mask = (unsigned)capacity - 1;
     hipLaunchKernelGGL(k_insert_rows, dim3(nb), dim3(TPB), 0, stream, coords, n_dev, n_max,
-                       (unsigned long long*)table_keys, table_vals, mask, table_shift(1), w.slot_of_row, status);
+                       (unsigned long long*)table_keys, table_vals, mask, w.slot_of_row, status);
     hipLaunchKernelGGL(k_flag_block_sums, dim3(nsb), dim3(SCAN_THREADS), 0, stream, w.slot_of_row, table_vals, n_dev,
                        n_max, w.scan_tmp);
     hipLaunchKernelGGL(k_flag_number, dim3(nsb), dim3(SCAN_THREADS), 0, stream, w.slot_of_row, table_vals, n_dev, n_max,
@@ -374,7 +348,7 @@ int coords_stride_impl(const int32_t* fine_coords, const int32_t* n_fine_dev, in
     const int nb = cdiv(n_fine_max, TPB), nsb = cdiv(n_fine_max, SCAN_TILE);
     const unsigned mask = (unsigned)capacity - 1;
     hipLaunchKernelGGL(k_insert_parents, dim3(nb), dim3(TPB), 0, stream, fine_coords, n_fine_dev, n_fine_max, stride_out,
-                       (unsigned long long*)table_keys, table_vals, mask, table_shift(stride_out), w.slot_of_row);
+                       (unsigned long long*)table_keys, table_vals, mask, w.slot_of_row);
     hipLaunchKernelGGL(k_flag_block_sums, dim3(nsb), dim3(SCAN_THREADS), 0, stream, w.slot_of_row, table_vals, n_fine_dev,
                        n_fine_max, w.scan_tmp);
     hipLaunchKernelGGL(k_flag_number, dim3(nsb), dim3(SCAN_THREADS), 0, stream, w.slot_of_row, table_vals, n_fine_dev,
@@ -405,16 +379,15 @@ extern "C" int pbn_coords_stride(const int32_t* fine_coords, const int32_t* n_fi
 }
 
 extern "C" int pbn_kernel_map(const int32_t* out_coords, const int32_t* n_out_dev, int n_out_max, const int32_t* offsets,
-                              int n_offsets, int table_stride, const uint64_t* table_keys, const int32_t* table_vals,
-                              int capacity, int32_t* nbr, pbn_stream_t stream_) {
+                              int n_offsets, const uint64_t* table_keys, const int32_t* table_vals, int capacity,
+                              int32_t* nbr, pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (n_out_max < 0 || n_offsets < 1 || table_stride < 1 || capacity < 1024 || (capacity & (capacity - 1))) return PBN_ERR_ARG;
+    if (n_out_max < 0 || n_offsets < 1 || capacity < 1024 || (capacity & (capacity - 1))) return PBN_ERR_ARG;
     if (n_out_max == 0) return PBN_OK;
     if (!out_coords || !offsets || !table_keys || !table_vals || !nbr) return PBN_ERR_ARG;
     const long long total = (long long)n_out_max * n_offsets;
     hipLaunchKernelGGL(k_kernel_map, dim3(cdiv(total, TPB)), dim3(TPB), 0, stream, out_coords, n_out_dev, n_out_max,
-                       offsets, n_offsets, (const unsigned long long*)table_keys, table_vals, (unsigned)capacity - 1,
-                       table_shift(table_stride), nbr);
+                       offsets, n_offsets, (const unsigned long long*)table_keys, table_vals, (unsigned)capacity - 1, nbr);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
@@ -437,8 +410,7 @@ namespace {
 __global__ __launch_bounds__(TPB) void k_kernel_map_cube(const int* __restrict__ out_coords, const int* n_dev, int n_max,
                                                         int ksize, int stride, int x_fastest,
                                                         const unsigned long long* __restrict__ keys,
-                                                        const int* __restrict__ vals, unsigned mask, int shift,
-                                                        int* __restrict__ nbr) {
+                                                        const int* __restrict__ vals, unsigned mask, int* __restrict__ nbr) {
     // grid-stride over the REAL row count: the launch only knows an upper bound (the input size), and the coarse levels
     // hold a few hundred rows of it
     const int K = ksize * ksize * ksize;
@@ -452,7 +424,7 @@ __global__ __launch_bounds__(TPB) void k_kernel_map_cube(const int* __restrict__
         const int4 cc = reinterpret_cast<const int4*>(out_coords)[row];
         const int x = cc.y + dx, y = cc.z + dy, z = cc.w + dz;
         int r = -1;
-        if (in_range(cc.x, x, y, z)) r = table_find(keys, vals, mask, pack4(cc.x, x, y, z), shift);
+        if (in_range(cc.x, x, y, z)) r = table_find(keys, vals, mask, pack4(cc.x, x, y, z));
         nbr[e] = r;
     }
 }
@@ -471,7 +443,7 @@ extern "C" int pbn_kernel_map_cube(const int32_t* out_coords, const int32_t* n_o
     const long long blocks = cdiv(total, TPB);
     hipLaunchKernelGGL(k_kernel_map_cube, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(TPB), 0, stream, out_coords, n_out_dev, n_out_max,
                        kernel_size, tensor_stride, x_fastest, (const unsigned long long*)table_keys, table_vals,
-                       (unsigned)capacity - 1, table_shift(tensor_stride), nbr);
+                       (unsigned)capacity - 1, nbr);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
@@ -519,7 +491,7 @@ namespace {
 // level-0 table of rows that are already unique: value = row id, coordinates copied, no numbering pass
 __global__ __launch_bounds__(TPB) void k_insert_identity(const int* __restrict__ coords, const int* n_dev, int n_max,
                                                         unsigned long long* __restrict__ keys, int* __restrict__ vals,
-                                                        unsigned mask, int shift, int* __restrict__ out_coords,
+                                                        unsigned mask, int* __restrict__ out_coords,
                                                         int* __restrict__ n_out) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     const int n = real_n(n_dev, n_max);
@@ -527,8 +499,8 @@ __global__ __launch_bounds__(TPB) void k_insert_identity(const int* __restrict__
     if (i >= n) return;
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
     reinterpret_cast<int4*>(out_coords)[i] = c;
+    unsigned h = hash64(pack4(c.x, c.y, c.z, c.w)) & mask;
     const unsigned long long key = pack4(c.x, c.y, c.z, c.w);
-    unsigned h = table_slot(key, shift, mask);
     while (atomicCAS(&keys[h], EMPTY_KEY, key) != EMPTY_KEY) h = (h + 1) & mask;
     vals[h] = i;
 }
@@ -566,7 +538,7 @@ int coords_insert_identity(const int32_t* coords, const int32_t* n_dev, int n_ma
                            int capacity, int32_t* out_coords, int32_t* n_out, hipStream_t stream) {
     if (n_max <= 0) return PBN_OK;
     hipLaunchKernelGGL(k_insert_identity, dim3(cdiv(n_max, TPB)), dim3(TPB), 0, stream, coords, n_dev, n_max,
-                       (unsigned long long*)keys, vals, (unsigned)capacity - 1, table_shift(1), out_coords, n_out);
+                       (unsigned long long*)keys, vals, (unsigned)capacity - 1, out_coords, n_out);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }

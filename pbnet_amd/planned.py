@@ -28,7 +28,7 @@ import torch
 from . import _native as N
 from . import pbnet_ops, stage_ops
 from .MinkowskiEngine import conventions as CV
-from .MinkowskiEngine.conv import _DT, _workspace
+from .MinkowskiEngine.conv import _DT, SPLITK_WORKSPACE_BYTES
 
 CNT = SimpleNamespace(POINTS=0, CLUSTERS=1, ENTRIES=2, ROWS=3, SCENES=4, PROPOSAL_ROWS=5, PROPOSALS=6, OVERFLOW=7, WORDS=16)
 OVF_NAMES = {1: "selected points", 2: "clusters", 4: "local-scene entries", 8: "local-scene rows",
@@ -148,7 +148,10 @@ class PlannedForward(object):
         nbytes = lib.pbn_unet_arena_bytes(plan["bufs"], plan["n_bufs"], n_rows, _DT[dt], offs)
         arena = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
         k3, k5, down, up = lin.tables()
-        ws = _workspace(dev)
+        # split-K scratch of THIS forward: the per-stream cache of the size-exact path must not be used here -- every graph
+        # capture of a process runs on torch's one shared capture stream, so a cached block would be handed from the private
+        # pool of one captured graph to the next and dangle once the first graph is released
+        ws = self._splitk_ws
         vp = ctypes.c_void_p
         N.check(lib.pbn_unet_forward_dev(plan["ops"], plan["n_ops"], plan["bufs"], plan["n_bufs"], n_rows,
                                          vp(lin.counts.data_ptr()), vp(padded.data_ptr()), cin_p, k3, k5, down, up,
@@ -180,6 +183,7 @@ class PlannedForward(object):
         n_pts, n_vox, nb = cap.n_points, cap.n_voxels, self.nb
         assert feat_voxel.shape[0] == n_vox and xyz_original.shape[0] == n_pts and feat_voxel.dtype == dt
         self._level_overflow = []
+        self._splitk_ws = torch.empty(SPLITK_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
         counts = torch.zeros(CNT.WORDS, dtype=torch.int32, device=dev)
         cptr = counts.data_ptr()
         cnt = lambda k: cptr + 4 * k
@@ -294,7 +298,7 @@ class PlannedForward(object):
         ovf = torch.stack(self._level_overflow).any().to(torch.int32) * 64
         counts[CNT.OVERFLOW:CNT.OVERFLOW + 1] |= ovf
         out.update(proposals_idx=prop_idx, proposals_offset=proposals_offset, alive_ids=alive_ids, proposals_ms=prop_ms,
-                   clt_scores=clt_scores, _keep=(lin1, lin2, lin3, res, feat2, feat3, point_feat_p))
+                   clt_scores=clt_scores, _keep=(lin1, lin2, lin3, res, feat2, feat3, point_feat_p, self._splitk_ws))
         return out
 
     # ---- the one read-back ------------------------------------------------------------------------------------------------
