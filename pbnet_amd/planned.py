@@ -36,6 +36,7 @@ OVF_NAMES = {1: "selected points", 2: "clusters", 4: "local-scene entries", 8: "
 MASK_THD = 0.45
 LOCAL_VOXEL = 0.02
 _DEBUG = os.environ.get("PBN_PLANNED_DEBUG", "0") == "1"
+_STOP = os.environ.get("PBN_PLANNED_STOP", "")      # debugging: end the launch sequence after the named stage
 
 
 def _dbg(stage, counts=None):
@@ -124,6 +125,7 @@ class PlannedForward(object):
         self.kmax = torch.tensor(model._k_max_list(), dtype=torch.int32, device=self.dev)
         self.nb = 3                                                    # PBNet.py:167-170: cluster_batch outside training
         self.graph = None
+        self._replay_stream = None
         # level capacities on the device (compared with the row counts of each pyramid; built here, not inside a capture)
         self._caps_t = {id(lv): torch.tensor([int(v) for v in lv], dtype=torch.int32, device=self.dev)
                         for lv in (cap.lv1, cap.lv2, cap.lv3)}
@@ -193,9 +195,13 @@ class PlannedForward(object):
         # ---- backbone + heads (PBNet.py:117-136) ----
         coords1 = xyz_voxel.to(torch.int32).contiguous()
         lin1 = _Lineage(coords1, n_vox, None, dev)
+        if _STOP == "prepare1":
+            return {"counts": counts, "_keep": (lin1, coords1)}
         feats1 = feat_voxel.contiguous()
         f = self._unet(m.MEUnet, lin1, cap.lv1, feats1, feats1.shape[1] * es)
         _dbg("backbone done", counts)
+        if _STOP == "backbone":
+            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
         v2p = v2p_index.long()
         v2p_z = lin1.inv_perm[v2p]                                   # Z-order row of every point's voxel
         point_feat_p = f[v2p_z]
@@ -209,6 +215,8 @@ class PlannedForward(object):
         out = {"sem_pred_p": sem_pred, "sem_pred_score_p": sem_score, "offset_pred_p": offset_p, "counts": counts}
 
         _dbg("heads done", counts)
+        if _STOP == "heads":
+            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
         # ---- class gate -> selection -> grouping (PBNet.py:151-179), sizes on the device ----
         n_cls = int(m.sem_num)
         n_seg = (n_cls - 2) * nb
@@ -221,6 +229,8 @@ class PlannedForward(object):
         res = pbnet_ops.cluster_device(ins_off, ins_orig, ins_sem, seg_len, m.radius, m.min_pts, capacity=True)
 
         _dbg("grouping done", counts)
+        if _STOP == "grouping":
+            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
         # ---- local scenes (PBNet.py:182-234): plan on the device, rows by one launch ----
         c_cap, e_cap, r_cap = int(cap.clusters), int(cap.entries), int(cap.rows)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -249,12 +259,16 @@ class PlannedForward(object):
             vp(feat2.data_ptr()), ld2, st()), "pbn_local_scene_rows_dev")
 
         _dbg("local scene rows done", counts)
+        if _STOP == "local scene rows":
+            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
         # ---- mask branch (PBNet.py:236-252) ----
         lin2 = _Lineage(coords2, r_cap, cnt(CNT.ROWS), dev)
         f2 = self._unet(m.D_Unet, lin2, cap.lv2, feat2, ld2 * es)
         mask_score = self._mlp(m.linear_binary, f2, lin2.inverse, lin2.inv_perm, r_cap, cnt(CNT.ROWS))      # [r_cap, 1]
 
         _dbg("mask branch done", counts)
+        if _STOP == "mask branch":
+            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
         # ---- proposals (PBNet.py:317-347) ----
         per_scene = torch.empty(c_cap, **i32)
         block_cnt = torch.empty(max(int(lib.pbn_select_blocks(r_cap)), 1), **i32)
@@ -276,6 +290,8 @@ class PlannedForward(object):
             N.ptr(coords3), vp(feat3.data_ptr()), st()), "pbn_proposal_rows_dev")
 
         _dbg("proposals done", counts)
+        if _STOP == "proposals":
+            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
         # ---- score branch (PBNet.py:255-279) ----
         lin3 = _Lineage(coords3, r_cap, cnt(CNT.PROPOSAL_ROWS), dev)
         f3 = self._unet(m.score_Unet, lin3, cap.lv3, feat3, c_in * es)
@@ -294,6 +310,8 @@ class PlannedForward(object):
         pooled = (mx + av).to(dt)
         clt_scores = stage_ops.mlp_rows(m.linear_IOU, pooled).view(-1)
         _dbg("score branch done", counts)
+        if _STOP == "score branch":
+            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
         # a level of one of the three pyramids that outgrew its capacity (rows were dropped): flag it
         ovf = torch.stack(self._level_overflow).any().to(torch.int32) * 64
         counts[CNT.OVERFLOW:CNT.OVERFLOW + 1] |= ovf
@@ -340,14 +358,26 @@ class PlannedForward(object):
         return self
 
     def replay(self, feat_voxel=None, xyz_voxel=None, xyz_original=None, v2p_index=None, teacher=None):
-        new = (feat_voxel, xyz_voxel, xyz_original, v2p_index)
-        for dst, src in zip(self.static_in, new):
-            if src is not None:
-                dst.copy_(src)
-        if teacher is not None:
-            for k, v in teacher.items():
-                self.static_teacher[k].copy_(v)
-        self.graph.replay()
+        """Copy new inputs (same shapes) into the static buffers and launch the graph.  The launch goes to a stream of
+        its own, joined with the caller's current stream by events on both sides: on this ROCm a graph launched on the legacy
+        default stream never completes once an eager kernel has read one of the graph's buffers between two replays
+        (reproduced with a graph that holds nothing but the coordinate pipeline, scripts/debug_stop2.py); on a non-default
+        stream the same sequence is fine."""
+        cur = torch.cuda.current_stream(self.dev)
+        if self._replay_stream is None:
+            self._replay_stream = torch.cuda.Stream(self.dev)
+        rs = self._replay_stream
+        rs.wait_stream(cur)
+        with torch.cuda.stream(rs):
+            new = (feat_voxel, xyz_voxel, xyz_original, v2p_index)
+            for dst, src in zip(self.static_in, new):
+                if src is not None:
+                    dst.copy_(src)
+            if teacher is not None:
+                for k, v in teacher.items():
+                    self.static_teacher[k].copy_(v)
+            self.graph.replay()
+        cur.wait_stream(rs)
         return self.static_out
 
 

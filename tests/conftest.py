@@ -32,7 +32,7 @@ def _hang_watchdog(request):
                    else os.devnull, "a")
         log.write("== %s\n" % request.node.nodeid)
         log.flush()
-        faulthandler.dump_traceback_later(240, exit=True, file=log)       # pytest captures stderr: write to a file instead
+        faulthandler.dump_traceback_later(int(os.environ.get("PBN_TEST_WATCHDOG", "240")), exit=True, file=log)       # pytest captures stderr: write to a file instead
         yield
         faulthandler.cancel_dump_traceback_later()
         log.close()

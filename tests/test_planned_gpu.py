@@ -167,7 +167,7 @@ def test_bench_scene_planned_bf16():
     _same_proposals(got, want, 2e-2)
 
     pf.capture(*_args(b), teacher=t)
-    for _ in range(2):
+    for _ in range(3):                      # outputs are READ by eager kernels between replays (what a serving loop does)
         rep = pf.finish(pf.replay())
         torch.cuda.synchronize()
         for a_, w_ in zip(rep["proposals"], got["proposals"]):
