@@ -320,19 +320,32 @@ class PlannedForward(object):
         return out
 
     # ---- the one read-back ------------------------------------------------------------------------------------------------
-    @staticmethod
-    def finish(out):
+    def finish(self, out):
         """Slice the capacity-sized outputs to their true sizes (one device->host copy of 16 ints).  Returns the dict of
-        PBNet.forward, or raises CapacityOverflow."""
+        PBNet.forward, or raises CapacityOverflow.  Outputs of a graph replay are COPIED out of the graph's buffers on the
+        replay stream: the caller never touches graph memory (see `replay`: eager kernels on the legacy default stream that
+        read it make the next launch of the graph hang on this ROCm)."""
+        from_graph = self.graph is not None and out is getattr(self, "static_out", None)
+        if from_graph:
+            cur = torch.cuda.current_stream(self.dev)
+            with torch.cuda.stream(self._replay_stream):
+                res = self._slice(out, clone=True)
+            cur.wait_stream(self._replay_stream)
+            return res
+        return self._slice(out, clone=False)
+
+    @staticmethod
+    def _slice(out, clone):
         c = out["counts"].cpu().tolist()
         if c[CNT.OVERFLOW]:
             raise CapacityOverflow(c[CNT.OVERFLOW])
         n_prop, n_rows = c[CNT.PROPOSALS], c[CNT.PROPOSAL_ROWS]
-        return {"sem_pred_p": out["sem_pred_p"], "sem_pred_score_p": out["sem_pred_score_p"],
-                "offset_pred_p": out["offset_pred_p"],
-                "proposals": (out["proposals_idx"][:n_rows], out["proposals_offset"][:n_prop + 1], out["alive_ids"][:n_prop],
-                              out["proposals_ms"][:n_rows]),
-                "clt_scores": out["clt_scores"][:n_prop], "counts": c}
+        f = (lambda t: t.clone()) if clone else (lambda t: t)
+        return {"sem_pred_p": f(out["sem_pred_p"]), "sem_pred_score_p": f(out["sem_pred_score_p"]),
+                "offset_pred_p": f(out["offset_pred_p"]),
+                "proposals": (f(out["proposals_idx"][:n_rows]), f(out["proposals_offset"][:n_prop + 1]),
+                              f(out["alive_ids"][:n_prop]), f(out["proposals_ms"][:n_rows])),
+                "clt_scores": f(out["clt_scores"][:n_prop]), "counts": c}
 
     def __call__(self, feat_voxel, xyz_voxel, xyz_original, v2p_index, teacher=None):
         with torch.no_grad():
