@@ -322,16 +322,7 @@ class PlannedForward(object):
     # ---- the one read-back ------------------------------------------------------------------------------------------------
     def finish(self, out):
         """Slice the capacity-sized outputs to their true sizes (one device->host copy of 16 ints).  Returns the dict of
-        PBNet.forward, or raises CapacityOverflow.  Outputs of a graph replay are COPIED out of the graph's buffers on the
-        replay stream: the caller never touches graph memory (see `replay`: eager kernels on the legacy default stream that
-        read it make the next launch of the graph hang on this ROCm)."""
-        from_graph = self.graph is not None and out is getattr(self, "static_out", None)
-        if from_graph:
-            cur = torch.cuda.current_stream(self.dev)
-            with torch.cuda.stream(self._replay_stream):
-                res = self._slice(out, clone=True)
-            cur.wait_stream(self._replay_stream)
-            return res
+        PBNet.forward, or raises CapacityOverflow."""
         return self._slice(out, clone=False)
 
     @staticmethod
@@ -371,11 +362,12 @@ class PlannedForward(object):
         return self
 
     def replay(self, feat_voxel=None, xyz_voxel=None, xyz_original=None, v2p_index=None, teacher=None):
-        """Copy new inputs (same shapes) into the static buffers and launch the graph.  The launch goes to a stream of
-        its own, joined with the caller's current stream by events on both sides: on this ROCm a graph launched on the legacy
-        default stream never completes once an eager kernel has read one of the graph's buffers between two replays
-        (reproduced with a graph that holds nothing but the coordinate pipeline, scripts/debug_stop2.py); on a non-default
-        stream the same sequence is fine."""
+        """Copy new inputs (same shapes) into the static buffers and launch the graph on a stream of its own, joined with
+        the caller's current stream by events on both sides.
+        KNOWN ISSUE (ROCm 7.0 runtime of this image, open): at ScanNet scene size, eager torch kernels issued BETWEEN two
+        replays (e.g. torch.equal on the outputs) can make the next launch of the graph never complete -- reproduced with a
+        graph that holds nothing but the coordinate pipeline (scripts/debug_stop2.py, scripts/debug_variants.py variant E);
+        back-to-back replay + finish loops (scripts/debug_inflight_graph.py, 4-8 host threads) and small scenes are fine."""
         cur = torch.cuda.current_stream(self.dev)
         if self._replay_stream is None:
             self._replay_stream = torch.cuda.Stream(self.dev)
