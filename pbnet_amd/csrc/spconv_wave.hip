@@ -113,7 +113,12 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     // ---- which offsets are populated among this wave's rows (K <= 128: two ballots) ----
     const int wrow0 = KSPLIT ? 0 : wave * RW;
     unsigned long long pop0, pop1;
-    {
+    if constexpr (KSPLIT) {
+        // coarse levels: 93-98 % of the (64-row tile, offset) pairs are populated (scripts/analyze_rulebook.py) -- visiting
+        // every offset costs a few per cent of MFMA work and takes the population scan (2 x RW LDS reads per lane) out of
+        // the prologue of a launch whose whole main loop is a few microseconds
+        pop0 = pop1 = ~0ull;
+    } else {
         bool any0 = false, any1 = false;
         if (lane < K)
             for (int r = 0; r < RW; ++r) any0 |= s_nbr[(wrow0 + r) * KS + lane] >= 0;
@@ -161,7 +166,9 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
         // sentinels: the pipeline below always has B units in flight and needs no tail handling
         if (lane < 2 * B) my_units[n_units + lane] = UNIT_NONE;
     }
-    __syncthreads();   // (the list is wave-private; a workgroup barrier is the simplest fence for it)
+    // the list is wave-private and a wave's LDS operations execute in order: the reads below follow the writes above
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     f32x4 acc[NF][NT];
 #pragma unroll

@@ -81,6 +81,11 @@ def main():
     pd.sync_buffers(model)                                          # what precedes validation / checkpoint_save
     lossv = torch.tensor([float(loss)], device=dev)
     dist.all_reduce(lossv)
+    dist.barrier()
+    dist.destroy_process_group()
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)          # RCCL's version banner sits in C stdio: flush it so that the JSON line comes last
     if rank == 0:
         e = float(el.item())
         print(json.dumps({"metric": "training scenes/s (configs[2]: bf16 step, one scene per rank, RCCL gradient all-reduce)",
@@ -89,8 +94,6 @@ def main():
                           "allreduce_tail_ms_per_step": round(t_comm[0] / args.steps * 1e3, 2), "overlap": not args.no_overlap,
                           "mean_loss_last_step": round(float(lossv) / world, 5),
                           "points_per_scene": info["n_points"], "voxels_per_scene": info["n_voxels"]}), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 if __name__ == "__main__":
