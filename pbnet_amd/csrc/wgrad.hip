@@ -56,36 +56,63 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
     const long long per_wave = (((s_hi - s_lo) + 3) / 4 + 3) & ~3LL;
     const long long w_lo = min(s_lo + per_wave * wave, s_hi), w_hi = min(w_lo + per_wave, s_hi);
 
-    const T* x = reinterpret_cast<const T*>(a.x);
-    const T* g = reinterpret_cast<const T*>(a.g);
+    // both slabs through buffer resources: 32-bit byte offsets (row * pitch + channel), one multiply + add per row instead of
+    // 64-bit pointer arithmetic per element; an absent pair / a channel past the tensor uses an out-of-range offset and
+    // reads zero.  (Slabs stay far below 4 GiB: pbn_spconv_forward already refuses 2 GiB.)
+    constexpr unsigned ESZ = (unsigned)sizeof(T);
+    constexpr unsigned NOREC = 0xfffffff0u, OOB = 0xfffffff8u;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)NOREC, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.g), 0, (int)NOREC, 0x00020000);
+    const unsigned ldx_b = (unsigned)a.ld_x * ESZ, ldg_b = (unsigned)a.ld_g * ESZ;
     const bool ci_ok = ci0 + j < a.cin;
+    const unsigned cx_b = (unsigned)(ci0 + j) * ESZ;
+    unsigned cg_b[NTW];
     bool co_ok[NTW];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) co_ok[t] = co0 + t * 16 + j < a.cout;
+    for (int t = 0; t < NTW; ++t) { co_ok[t] = co0 + t * 16 + j < a.cout; cg_b[t] = (unsigned)(co0 + t * 16 + j) * ESZ; }
     f32x4 acc[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (long long p0 = w_lo; p0 < w_hi; p0 += 8) {       // two MFMA steps (2 x 4 pairs) per trip: independent loads
-        float av[2], bv[2][NTW];
+    auto ld = [&](__amdgpu_buffer_rsrc_t rs, unsigned off) -> float {
+        if constexpr (sizeof(T) == 4) return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+        else {
+            const unsigned short h = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
+            if constexpr (__is_same(T, __hip_bfloat16)) return __uint_as_float((unsigned)h << 16);
+            else return __half2float(__builtin_bit_cast(__half, h));
+        }
+    };
+    // Blocks of 64 pairs: ONE coalesced index load per lane and block (lane l holds pair p0 + l; the next block's indices are
+    // fetched a block ahead), the 16 MFMA steps of the block take their row indices by lane shuffles and issue all their
+    // operand loads up front (16 x (1 + NTW) independent loads per lane), then the 64 MFMAs run behind them: two dependent
+    // memory latencies per 64 MFMAs.
+    auto load_idx = [&](long long p, int& ri, int& ro) {
+        ri = -1; ro = -1;
+        if (p < w_hi) {
+            if (a.in_idx) { ri = (int)a.in_idx[p]; ro = (int)a.out_idx[p]; }
+            else { ri = (int)p; ro = (int)p; }
+        }
+    };
+    int ri_n, ro_n;
+    load_idx(w_lo + lane, ri_n, ro_n);
+    for (long long p0 = w_lo; p0 < w_hi; p0 += 64) {
+        const int ri = ri_n, ro = ro_n;
+        load_idx(p0 + 64 + lane, ri_n, ro_n);
+        float av[16], bv[16][NTW];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const long long p = p0 + h * 4 + kb;
-            long long ri = -1, ro = -1;
-            if (p < w_hi) {
-                if (a.in_idx) { ri = a.in_idx[p]; ro = a.out_idx[p]; }
-                else { ri = p; ro = p; }
-            }
-            const bool ok = ri >= 0;
-            av[h] = (ok && ci_ok) ? widen<T>(x + (size_t)ri * a.ld_x + ci0 + j) : 0.f;
+        for (int st = 0; st < 16; ++st) {
+            const int src = st * 4 + kb;
+            const int r_i = __shfl(ri, src, 64), r_o = __shfl(ro, src, 64);
+            const bool ok = r_i >= 0;
+            av[st] = ld(rs_x, (ok && ci_ok) ? (unsigned)r_i * ldx_b + cx_b : OOB);
+            const unsigned gbase = (unsigned)r_o * ldg_b;
 #pragma unroll
-            for (int t = 0; t < NTW; ++t)
-                bv[h][t] = (ok && co_ok[t]) ? widen<T>(g + (size_t)ro * a.ld_g + co0 + t * 16 + j) : 0.f;
+            for (int t = 0; t < NTW; ++t) bv[st][t] = ld(rs_g, (ok && co_ok[t]) ? gbase + cg_b[t] : OOB);
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int st = 0; st < 16; ++st)
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h], bv[h][t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv[st][t], acc[t], 0, 0, 0);
     }
     // waves 1..3 -> LDS, wave 0 adds them in wave order and stores.  D layout: column = lane & 15 (co), row = kb * 4 + r (ci)
     if (wave > 0) {
