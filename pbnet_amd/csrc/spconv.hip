@@ -37,6 +37,19 @@ constexpr int CGMAX = 4;  // channel chunks (steps) per group
 
 #define PBN_LDS_ADDR(p) ((unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)(p)))
 
+// Cycle stamps of the main loop (debug build only: make timing -> libpbnet_hip_timing.so, scripts/conv_timing.py):
+// the middle workgroup's four waves record s_memtime at 8 points of their first 64 groups.
+#ifdef PBN_CONV_TIMING
+__device__ unsigned g_conv_timing[4 * 64 * 8 + 8];
+#define PBN_STAMP(POS, I)                                                                                             \
+    if (timed_ && lane == 0 && (POS) - g_lo < 64)                                                                     \
+        s_time[(wave * 64 + ((POS) - g_lo)) * 8 + (I)] = (unsigned)__builtin_readcyclecounter();
+#define PBN_TIMING_SKIP_DMA if (a.dbg & 64) continue   /* experiment: no weight copies at all (results are garbage) */
+#else
+#define PBN_STAMP(POS, I)
+#define PBN_TIMING_SKIP_DMA
+#endif
+
 // Reduction axis: STEP s = 4 x 16-byte vectors of the flattened (offset, channel) axis; GROUP = cg consecutive steps
 // of ONE kernel offset (cg = largest divisor <= 4 of the steps per offset; 1 when an offset is narrower than a step).
 //
@@ -76,6 +89,11 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform for the compiler
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
     const int row0 = xcd_tile(blockIdx.x, gridDim.x) * TM;
+#ifdef PBN_CONV_TIMING
+    __shared__ unsigned s_time[4 * 64 * 8];
+    const bool timed_ = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0;
+    if (timed_) for (int e = tid; e < 4 * 64 * 8; e += CONV_TPB) s_time[e] = 0u;
+#endif
     if (row0 >= n) return;
     const int tile0 = blockIdx.y * NT;
 
@@ -222,6 +240,7 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
         _Pragma("unroll") for (int i = 0; i < ((CG) * NT + 3) / 4; ++i) {                                             \
             const int p_ = min(wave + 4 * i, (CG) * NT - 1);                                                          \
             const int c_ = p_ / NT, t_ = p_ - c_ * NT;                                                                \
+            PBN_TIMING_SKIP_DMA;                                                                                      \
             unsigned keep_;                                                                                           \
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"                                        \
                          "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"                               \
@@ -240,8 +259,11 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
 #define PBN_GROUP(POS, CG)                                                                                            \
     {                                                                                                                 \
         constexpr int PW_ = ((CG) * NT + 3) / 4;                                                                      \
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier"                                                               \
-                     : : "n"((CG) * NF + (DEPTH - 1) * (PW_ + (CG) * NF)) : "memory");                                \
+        PBN_STAMP(POS, 0);                                                                                            \
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"((CG) * NF + (DEPTH - 1) * (PW_ + (CG) * NF)) : "memory");          \
+        PBN_STAMP(POS, 1);                                                                                            \
+        asm volatile("s_barrier" : : : "memory");                                                                     \
+        PBN_STAMP(POS, 2);                                                                                            \
         const bool active_ = (fcur & my_bits) && !(a.dbg & 2);                                                        \
         const bool more_ = (POS) + 1 < ng;                                                                            \
         const u32x4* cur_ = s_w + slot * ((CG) * NT * 64);                                                            \
@@ -256,12 +278,15 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
             fcur = more_ ? fnext_ : 0u;                                                                               \
             PBN_GROUP_ROWS((POS) + 1, gnext_, more_, vnext_, CG);                                                     \
         }                                                                                                             \
+        PBN_STAMP(POS, 3);                                                                                            \
         /* the asm statements that define x[][] stay on the straight-line path: inside a branch the compiler would */ \
         /* merge them through register copies, i.e. read registers whose loads are still in flight                 */ \
         u32x4 wf_[2][NT];                                                                                             \
         if (active_) PBN_LOAD_WF(wf_[0], cur_, 0);                                                                    \
         _Pragma("unroll") for (int c = 0; c < (CG); ++c) {                                                            \
             PBN_WAIT_X(c, ((CG) - 1) * NF + PW_);                                                                     \
+            if (c == 0) { PBN_STAMP(POS, 4); }                                                                        \
+            if (c == (CG) - 1) { PBN_STAMP(POS, 5); }                                                                 \
             if (active_) {                                                                                            \
                 if (c + 1 < (CG)) PBN_LOAD_WF(wf_[(c + 1) & 1], cur_, c + 1);                                         \
                 _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
@@ -270,6 +295,7 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
             }                                                                                                         \
             PBN_LOAD_X(vnext_, c);                                                                                    \
         }                                                                                                             \
+        PBN_STAMP(POS, 6);                                                                                            \
     }
     // prologue: the same issue pattern as DEPTH loop bodies (the gathers behind all but the last DMA are dummies with
     // out-of-range offsets) so that the loop's wait counts hold from the first group on
@@ -301,6 +327,13 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
             default: PBN_MAINLOOP(1); break;
         }
     }
+#ifdef PBN_CONV_TIMING
+    __syncthreads();
+    if (timed_) {
+        for (int e = tid; e < 4 * 64 * 8; e += CONV_TPB) g_conv_timing[e] = s_time[e];
+        if (tid == 0) { g_conv_timing[4 * 64 * 8] = (unsigned)(ng - g_lo); g_conv_timing[4 * 64 * 8 + 1] = (unsigned)cg; }
+    }
+#endif
 #undef PBN_MAINLOOP
 #undef PBN_GROUP
 #undef PBN_LOAD_WF
@@ -535,6 +568,15 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, cons
         default: return PBN_ERR_ARG;
     }
 }
+
+#ifdef PBN_CONV_TIMING
+// debug build only: the stamps of the last k_spconv launch -> host (4 waves x 64 groups x 8 stamps, then groups run, cg)
+extern "C" int pbn_conv_timing_read(unsigned* host) {
+    PBN_HIP_CHECK(hipDeviceSynchronize());
+    PBN_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(pbn::g_conv_timing), sizeof(unsigned) * (4 * 64 * 8 + 8)));
+    return PBN_OK;
+}
+#endif
 
 extern "C" int pbn_gather_rows(const void* in, int ld_in_bytes, const int64_t* idx, int n, int row_bytes, void* out,
                                int ld_out_bytes, pbn_stream_t stream_) {

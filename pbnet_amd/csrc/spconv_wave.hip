@@ -324,6 +324,9 @@ int pick_cfg(const ConvArgs& a) {
     const long long rows = a.n_out;
     // K-split candidates from the widest tile down; the first one that gives the chip one round of workgroups wins
     // (fitted on scripts/probe_wave.py: 1202 on the 791-row level, 1204 / 1404 on the 3.5 k- and 14.7 k-row levels)
+    // stem-like layers (a 16/32-byte input row, K = 125): 32 rows x 32 channels per workgroup measured best at every size
+    // (146 k rows: 44.8 us against 68.1 for 64 rows and 72.6 for the workgroup-tile kernel)
+    if (a.vpo <= 2 && a.K >= 64 && ntt % 2 == 0) return 1202;
     int best = 0;
     long long best_wgs = -1;
     for (int cfg : {1404, 1204, 1402, 1202, 1401, 1201}) {
@@ -372,6 +375,7 @@ bool wave_family_wanted(const ConvArgs& a, int dtype) {
     if (a.K > 128) return false;
     if (fam == 0) return false;
     if (fam == 1) return true;
+    if (a.vpo <= 2 && a.K >= 64 && !a.row_perm) return true;   // the k = 5 stem: rulebook-bound, no weight reuse to speak of
     const double elems_per_step = 4.0 * (dtype == PBN_F32 ? 4.0 : 8.0);
     const double dense = (double)a.n_out * a.n_steps * elems_per_step * a.ntiles_total * 16.0;
     return a.n_out < max_rows && dense <= max_macs;
