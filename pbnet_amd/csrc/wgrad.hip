@@ -12,16 +12,14 @@
 //     contiguous quarter of the workgroup's pair range; the four partial tiles are summed through LDS in wave order;
 //   * grid = (tile strips, offsets, pair splits); split partials go to a workspace and are summed in split order by
 //     k_wgrad_reduce: fixed summation order everywhere -> bit-identical run to run (no atomics).
-// Rate: the f32-input MFMA runs at 1/16 of the bf16 rate (MI355X_MICROARCH.md); the bf16 form needs both operands
-// transposed through LDS (ds_read_b64_tr_b16) and is the next step for this kernel.
-#include "pbn_common.h"
-#include <hip/hip_bf16.h>
-#include <hip/hip_fp16.h>
+// Rate: the f32-input MFMA runs at 1/16 of the bf16 rate (MI355X_MICROARCH.md).  16-bit slabs with 16-byte aligned rows
+// therefore take k_wgrad16 below: rows are gathered with 16-byte loads into LDS and reach v_mfma_f32_16x16x32_{bf16,f16}
+// through the hardware transpose read (ds_read_b64_tr_b16); k_wgrad serves fp32 slabs and unaligned 16-bit rows.
+#include "spconv_common.h"
 
 namespace pbn {
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int NTW = 4;   // output-channel tiles per wave
 
 template <typename T> __device__ __forceinline__ float widen(const T* p);
@@ -137,6 +135,170 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
         }
 }
 
+// ---- 16-bit slabs: pairs are the MFMA's K axis, so both operands must be read TRANSPOSED (8 consecutive pairs of one
+// channel per lane).  A step = 32 pairs: the workgroup's 256 threads gather the pairs' rows of both slabs with 16-byte
+// loads (whole 8-channel chunks, coalesced along the row) one step ahead, store them row-major in LDS, and every wave
+// builds its operands with ds_read_b64_tr_b16 -- a 16-lane group reads a [4 pairs][16 channels] block and each lane
+// receives 4 pairs of one channel; two reads make the 8-pair operand of v_mfma_f32_16x16x32.
+//   * workgroup = 2 x 2 waves; a wave owns WA x WB 16-channel tiles of dW[k]: the workgroup covers 32 WA x 32 WB channels;
+//   * the pair -> MFMA k mapping is k = 8 kg + j  <->  LDS row 4 kg + (j & 3) + 16 (j >> 2) (the same for both operands, so
+//     the contraction is unchanged): with a row pitch of 16 x odd elements the 8 rows a 32-lane half reads per LDS cycle
+//     fall into 8 distinct 8-bank ranges -- conflict-free (MI355X_MICROARCH.md, LDS table);
+//   * one barrier per step (two LDS images), index lists fetched two steps ahead, gathers one step ahead.
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+constexpr int W16_SP = 32;   // pairs per step
+__host__ __device__ constexpr int w16_pitch(int channels) { return ((channels / 16) | 1) * 16; }
+
+template <typename T, int WA, int WB>
+__global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
+    constexpr int CIT = 2 * WA, COT = 2 * WB;               // 16-channel tiles per workgroup
+    constexpr int PX = w16_pitch(CIT * 16), PG = w16_pitch(COT * 16);
+    constexpr int CXC = CIT * 2, CGC = COT * 2;             // 16-byte chunks per row
+    constexpr int NCH = W16_SP * (CXC + CGC);
+    constexpr int NPT = (NCH + 255) / 256;                  // chunks per thread and step
+    __shared__ __attribute__((aligned(16))) unsigned short s_x[2][W16_SP * PX];
+    __shared__ __attribute__((aligned(16))) unsigned short s_g[2][W16_SP * PG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kg = lane >> 4;
+    const int k = blockIdx.y;
+    const int cib = blockIdx.x / a.co_groups, cob = blockIdx.x % a.co_groups;
+    const int ci_base = cib * (CIT * 16), co_base = cob * (COT * 16);
+    const int wa = wave >> 1, wb = wave & 1;
+
+    long long p_lo, p_hi;
+    if (a.seg_begin) { p_lo = (long long)a.seg_begin[k] * a.segment; p_hi = (long long)a.seg_begin[k + 1] * a.segment; }
+    else { p_lo = 0; p_hi = a.n_pairs; }
+    const long long len = p_hi - p_lo;
+    const long long per_split = ((len + a.splits - 1) / a.splits + W16_SP - 1) & ~(long long)(W16_SP - 1);
+    const long long s_lo = min(p_lo + per_split * blockIdx.z, p_hi), s_hi = min(s_lo + per_split, p_hi);
+    const int steps = (int)((s_hi - s_lo + W16_SP - 1) / W16_SP);
+
+    constexpr unsigned NOREC = 0xfffffff0u, OOB = 0xfffffff8u;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)NOREC, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.g), 0, (int)NOREC, 0x00020000);
+    const unsigned ldx_b = (unsigned)a.ld_x * 2u, ldg_b = (unsigned)a.ld_g * 2u;
+    const int cin8 = (a.cin + 7) & ~7, cout8 = (a.cout + 7) & ~7;   // whole chunks inside the row (ld >= these: checked by the host)
+
+    // this thread's chunks: slab, row of the step, byte offset inside the slab row (or "no such channel"), LDS element
+    int c_row[NPT], c_lds[NPT];
+    unsigned c_col[NPT];
+    bool c_isx[NPT], c_ok[NPT];
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) {
+        const int q = tid + 256 * e;
+        c_isx[e] = q < W16_SP * CXC;
+        const int qq = c_isx[e] ? q : q - W16_SP * CXC;
+        const int per = c_isx[e] ? CXC : CGC;
+        const int row = qq / per, cc = qq - row * per;
+        c_row[e] = row;
+        const int ch = (c_isx[e] ? ci_base : co_base) + cc * 8;
+        c_ok[e] = q < NCH && ch < (c_isx[e] ? cin8 : cout8);
+        c_col[e] = (unsigned)ch * 2u;
+        c_lds[e] = row * (c_isx[e] ? PX : PG) + cc * 8;
+        if (q >= NCH) c_lds[e] = -1;
+    }
+    auto load_idx = [&](int step, int (&idx)[NPT]) {
+#pragma unroll
+        for (int e = 0; e < NPT; ++e) {
+            const long long p = s_lo + (long long)step * W16_SP + c_row[e];
+            idx[e] = -1;
+            if (p < s_hi && c_ok[e]) idx[e] = a.in_idx ? (int)(c_isx[e] ? a.in_idx[p] : a.out_idx[p]) : (int)p;
+        }
+    };
+    auto gather = [&](const int (&idx)[NPT], u32x4 (&v)[NPT]) {
+#pragma unroll
+        for (int e = 0; e < NPT; ++e) {
+            const unsigned off = idx[e] >= 0 ? (unsigned)idx[e] * (c_isx[e] ? ldx_b : ldg_b) + c_col[e] : OOB;
+            v[e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(c_isx[e] ? rs_x : rs_g, (int)off, 0, 0));
+        }
+    };
+    auto stage = [&](int buf, const u32x4 (&v)[NPT]) {
+#pragma unroll
+        for (int e = 0; e < NPT; ++e) {
+            if (c_lds[e] < 0) continue;
+            unsigned short* dst = (c_isx[e] ? s_x[buf] : s_g[buf]) + c_lds[e];
+            *reinterpret_cast<u32x4*>(dst) = v[e];
+        }
+    };
+
+    f32x4 acc[WA][WB];
+#pragma unroll
+    for (int ta = 0; ta < WA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < WB; ++tb) acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (steps > 0) {
+        int idx_a[NPT], idx_b[NPT];
+        u32x4 v[NPT];
+        load_idx(0, idx_a);
+        load_idx(1, idx_b);
+        gather(idx_a, v);
+        stage(0, v);
+        __syncthreads();
+        // per-lane LDS element offsets of the two transpose reads of tile 0 (see the row mapping above)
+        const int rd_x = (kg * 4 + (i >> 2)) * PX + (wa * WA) * 16 + (i & 3) * 4;
+        const int rd_g = (kg * 4 + (i >> 2)) * PG + (wb * WB) * 16 + (i & 3) * 4;
+        for (int st = 0; st < steps; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < steps) gather(idx_b, v);          // in flight behind this step's MFMAs
+            load_idx(st + 2, idx_b);
+            u32x4 fa[WA], fb[WB];
+#pragma unroll
+            for (int ta = 0; ta < WA; ++ta) {
+                const unsigned short* src = s_x[buf] + rd_x + ta * 16;
+                const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(src));
+                const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(src + 16 * PX));
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                fa[ta] = u32x4{l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+            for (int tb = 0; tb < WB; ++tb) {
+                const unsigned short* src = s_g[buf] + rd_g + tb * 16;
+                const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(src));
+                const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(src + 16 * PG));
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                fb[tb] = u32x4{l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+            for (int ta = 0; ta < WA; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < WB; ++tb) mfma_step<T>(fa[ta], fb[tb], acc[ta][tb]);
+            if (st + 1 < steps) stage(buf ^ 1, v);
+            __syncthreads();
+        }
+    }
+    // D layout: column = lane & 15 (co), row = kg * 4 + r (ci)
+    float* out = a.out + ((size_t)blockIdx.z * a.K + k) * (size_t)a.cin * a.cout;
+#pragma unroll
+    for (int ta = 0; ta < WA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < WB; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci_base + (wa * WA + ta) * 16 + kg * 4 + r, co = co_base + (wb * WB + tb) * 16 + i;
+                if (ci < a.cin && co < a.cout) out[(size_t)ci * a.cout + co] = acc[ta][tb][r];
+            }
+}
+
+template <typename T, int WA>
+void launch16_b(const WgradArgs& a, int wb, dim3 grid, hipStream_t stream) {
+    switch (wb) {
+        case 1: hipLaunchKernelGGL((k_wgrad16<T, WA, 1>), grid, dim3(256), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((k_wgrad16<T, WA, 2>), grid, dim3(256), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((k_wgrad16<T, WA, 3>), grid, dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL((k_wgrad16<T, WA, 4>), grid, dim3(256), 0, stream, a); break;
+    }
+}
+template <typename T>
+void launch16(const WgradArgs& a, int wa, int wb, dim3 grid, hipStream_t stream) {
+    switch (wa) {
+        case 1: launch16_b<T, 1>(a, wb, grid, stream); break;
+        case 2: launch16_b<T, 2>(a, wb, grid, stream); break;
+        case 3: launch16_b<T, 3>(a, wb, grid, stream); break;
+        default: launch16_b<T, 4>(a, wb, grid, stream); break;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int splits, long long n,
                                                      float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -174,8 +336,21 @@ extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g
     WgradArgs a;
     a.x = x; a.g = g; a.in_idx = (const long long*)in_idx; a.out_idx = (const long long*)out_idx; a.seg_begin = seg_begin;
     a.ld_x = ld_x; a.ld_g = ld_g; a.cin = cin; a.cout = cout; a.K = n_offsets; a.segment = segment; a.n_pairs = n_pairs_total;
-    a.co_groups = cdiv(cout, NTW * 16);
-    const int strips = cdiv(cin, 16) * a.co_groups;
+    // 16-bit slabs whose rows can be read in 16-byte chunks take the bf16/f16 matrix-core form (k_wgrad16)
+    static const int form_env = getenv("PBN_WGRAD_FORM") ? atoi(getenv("PBN_WGRAD_FORM")) : 16;   // 32: always the f32-MFMA form
+    const bool form16 = form_env == 16 && dtype != PBN_F32 && (ld_x % 8) == 0 && (ld_g % 8) == 0 &&
+                        ld_x >= ((cin + 7) & ~7) && ld_g >= ((cout + 7) & ~7) && (((uintptr_t)x | (uintptr_t)g) & 15) == 0;
+    int wa = 0, wb = 0, strips;
+    if (form16) {
+        const int cit = cdiv(cin, 16), cot = cdiv(cout, 16);
+        wa = cit >= 7 ? 4 : (cit + 1) / 2;            // waves are 2 x 2: a workgroup covers 2 wa x 2 wb tiles
+        wb = cot >= 7 ? 4 : (cot + 1) / 2;
+        a.co_groups = cdiv(cot, 2 * wb);
+        strips = cdiv(cit, 2 * wa) * a.co_groups;
+    } else {
+        a.co_groups = cdiv(cout, NTW * 16);
+        strips = cdiv(cin, 16) * a.co_groups;
+    }
     // pair splits: enough workgroups for the chip (~2048), at least ~512 pairs per workgroup, bounded by the workspace
     const long long pairs_per_offset = n_pairs_total / n_offsets + 1;
     long long splits = 2048 / ((long long)strips * n_offsets) + 1;
@@ -187,11 +362,16 @@ extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g
     a.splits = (int)splits;
     a.out = splits > 1 ? (float*)workspace : dw;
     const dim3 grid(strips, n_offsets, (unsigned)splits);
-    switch (dtype) {
-        case PBN_F32: hipLaunchKernelGGL(k_wgrad<float>, grid, dim3(256), 0, stream, a); break;
-        case PBN_BF16: hipLaunchKernelGGL(k_wgrad<__hip_bfloat16>, grid, dim3(256), 0, stream, a); break;
-        case PBN_F16: hipLaunchKernelGGL(k_wgrad<__half>, grid, dim3(256), 0, stream, a); break;
-        default: return PBN_ERR_ARG;
+    if (form16) {
+        if (dtype == PBN_BF16) launch16<__hip_bfloat16>(a, wa, wb, grid, stream);
+        else launch16<__half>(a, wa, wb, grid, stream);
+    } else {
+        switch (dtype) {
+            case PBN_F32: hipLaunchKernelGGL(k_wgrad<float>, grid, dim3(256), 0, stream, a); break;
+            case PBN_BF16: hipLaunchKernelGGL(k_wgrad<__hip_bfloat16>, grid, dim3(256), 0, stream, a); break;
+            case PBN_F16: hipLaunchKernelGGL(k_wgrad<__half>, grid, dim3(256), 0, stream, a); break;
+            default: return PBN_ERR_ARG;
+        }
     }
     if (splits > 1)
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n_out, 256)), dim3(256), 0, stream, (const float*)workspace, (int)splits,
