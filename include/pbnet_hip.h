@@ -236,6 +236,21 @@ int pbn_bn_train_backward(const void* x, int ld_x, const void* dy, int ld_dy, in
                           const float* weight, const float* save_mean, const float* save_invstd, void* dx, int ld_dx,
                           float* dweight, float* dbias, void* workspace, size_t workspace_bytes, pbn_stream_t stream);
 
+/* The same passes with the tail of the reference's blocks fused in (Mink.py:293-350, resnet block: conv -> bn -> relu and
+ * conv -> bn -> += residual -> relu):
+ *   forward : y = act(bn(x) [+ residual]) with act = max(., 0) when relu != 0 (residual NULL = none);
+ *   backward: g = dy where y > 0 else 0 (y = the forward output; NULL = no activation), dx / dweight / dbias from g,
+ *             dres (NULL = not wanted) = g, the gradient of the residual branch.
+ * Statistics, running buffers, workspace, summation order and error codes as pbn_bn_train_forward / _backward. */
+int pbn_bn_act_train_forward(const void* x, int ld_x, int n, int channels, int dtype, const float* weight, const float* bias,
+                             float eps, float momentum, float* running_mean, float* running_var, const void* residual,
+                             int ld_res, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, void* workspace,
+                             size_t workspace_bytes, pbn_stream_t stream);
+int pbn_bn_act_train_backward(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, int n, int channels,
+                              int dtype, const float* weight, const float* save_mean, const float* save_invstd, void* dx,
+                              int ld_dx, void* dres, int ld_dres, float* dweight, float* dbias, void* workspace,
+                              size_t workspace_bytes, pbn_stream_t stream);
+
 /* Offset-major pair lists of an output-stationary map (training, BASELINE configs[2]): the rule pairs of ME's
  * convolution weight gradient, dW[k] = sum over pairs (i, o) of offset k of x[i]^T g[o].
  *   pbn_rulebook_pair_counts : table int32[pbn_rulebook_pair_blocks(n), K] (per-block prefix counts, kept for the fill)

@@ -2,7 +2,7 @@
 import torch.nn as nn
 
 from ..conv import MinkowskiConvolution
-from ..nn import MinkowskiBatchNorm, MinkowskiReLU
+from ..nn import MinkowskiBatchNorm, MinkowskiReLU, bn_act
 
 
 class BasicBlock(nn.Module):
@@ -21,17 +21,14 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        # the reference's block (conv -> bn -> relu -> conv -> bn -> += residual -> relu); bn_act runs each bn with its
+        # tail as one pass when the native training path is on, and the separate modules otherwise
         residual = x
-        out = self.conv1(x)
-        out = self.norm1(out)
-        out = self.relu(out)
+        out = bn_act(self.norm1, self.conv1(x))
         out = self.conv2(out)
-        out = self.norm2(out)
         if self.downsample is not None:
             residual = self.downsample(x)
-        out = out.replace_feature(out.F + residual.F)
-        out = self.relu(out)
-        return out
+        return bn_act(self.norm2, out, residual=residual)
 
 
 class Bottleneck(nn.Module):

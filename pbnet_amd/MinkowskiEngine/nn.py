@@ -61,22 +61,114 @@ class _BatchNormTrainFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class _BatchNormActTrainFn(torch.autograd.Function):
+    """Train-mode batch norm with the tail of the reference's blocks fused in (Mink.py:293-350: conv -> bn -> relu,
+    conv -> bn -> += residual -> relu): y = relu(bn(x) [+ residual]) in the normalisation's apply pass; the backward masks
+    dy with (y > 0) while it reads it and hands the masked gradient to the residual branch (pbn_bn_act_train_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, eps, momentum, relu):
+        from .. import _native as N
+        n, c = int(x.shape[0]), int(x.shape[1])
+        y = torch.empty(n, c, dtype=x.dtype, device=x.device)
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = _bn_workspace(x.device, c)
+        N.check(N.lib().pbn_bn_act_train_forward(
+            N.c_vp(x.data_ptr()), x.stride(0), n, c, _DT[x.dtype], N.ptr(weight), N.ptr(bias), float(eps), float(momentum),
+            N.ptr(running_mean), N.ptr(running_var), None if residual is None else N.c_vp(residual.data_ptr()),
+            0 if residual is None else residual.stride(0), int(bool(relu)), N.c_vp(y.data_ptr()), c, N.ptr(mean), N.ptr(invstd),
+            N.c_vp(ws.data_ptr()), ws.numel(), N.current_stream()), "pbn_bn_act_train_forward")
+        ctx.save_for_backward(x, weight, mean, invstd, y if relu else None)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _native as N
+        x, weight, mean, invstd, y = ctx.saved_tensors
+        n, c = int(x.shape[0]), int(x.shape[1])
+        if dy.dtype != x.dtype or not _rows_ok(dy):
+            dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty(n, c, dtype=x.dtype, device=x.device)
+        want_res = ctx.has_res and ctx.needs_input_grad[3]
+        # without an activation the residual branch receives dy itself: no copy
+        dres = torch.empty(n, c, dtype=x.dtype, device=x.device) if (want_res and y is not None) else None
+        need_w = weight is not None and ctx.needs_input_grad[1]
+        dw = torch.empty(c, dtype=torch.float32, device=x.device) if need_w else None
+        db = torch.empty(c, dtype=torch.float32, device=x.device) if (weight is not None and ctx.needs_input_grad[2]) else None
+        ws = _bn_workspace(x.device, c)
+        N.check(N.lib().pbn_bn_act_train_backward(
+            N.c_vp(x.data_ptr()), x.stride(0), N.c_vp(dy.data_ptr()), dy.stride(0), None if y is None else N.c_vp(y.data_ptr()),
+            0 if y is None else y.stride(0), n, c, _DT[x.dtype], N.ptr(weight), N.ptr(mean), N.ptr(invstd), N.c_vp(dx.data_ptr()), c,
+            None if dres is None else N.c_vp(dres.data_ptr()), c, N.ptr(dw), N.ptr(db), N.c_vp(ws.data_ptr()), ws.numel(),
+            N.current_stream()), "pbn_bn_act_train_backward")
+        if want_res and dres is None:
+            dres = dy
+        return dx, dw, db, dres, None, None, None, None, None
+
+
+def bn_act(norm, x, residual=None, relu=True):
+    """relu(norm(x) [+ residual]) of the reference's blocks as ONE pass each way when `norm` (a MinkowskiBatchNorm) is
+    training on the native path; the separate modules otherwise (same values: norm -> += residual -> relu)."""
+    f, bn = x.F, norm.bn
+    res = None if residual is None else residual.F
+    if norm.NATIVE_TRAIN and norm.FUSE_ACT and bn.training and f.is_cuda and bn.momentum is not None and f.dtype in _DT \
+            and _rows_ok(f) and (bn.weight is None or bn.weight.dtype == torch.float32) \
+            and (res is None or (res.dtype == f.dtype and _rows_ok(res) and res.shape == f.shape)):
+        norm._tick()
+        rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+        return x.replace_feature(_BatchNormActTrainFn.apply(f, bn.weight, bn.bias, res, rm, rv, bn.eps, bn.momentum, relu))
+    out = norm(x)
+    if residual is not None:
+        out = out.replace_feature(out.F + residual.F)
+    return out.replace_feature(torch.relu(out.F)) if relu else out
+
+
+class _TickedBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d whose num_batches_tracked increments are counted on the host and applied when somebody looks at the
+    buffer (attribute access, state_dict): one tiny launch per layer and step less on the native training path."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.__dict__["_pending_ticks"] = 0
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_ticks())
+
+    def flush_ticks(self):
+        t = self.__dict__.get("_pending_ticks", 0)
+        if t:
+            self.__dict__["_pending_ticks"] = 0
+            buf = self._buffers.get("num_batches_tracked")
+            if buf is not None:
+                buf.add_(t)
+
+    def __getattr__(self, name):
+        if name == "num_batches_tracked":
+            self.flush_ticks()
+        return super().__getattr__(name)
+
+
 class MinkowskiBatchNorm(nn.Module):
     """ME.MinkowskiBatchNorm: `self.bn = nn.BatchNorm1d` on .F (Mink.py:71-73 reaches into `.bn`)."""
 
     NATIVE_TRAIN = True          # train-mode statistics / normalisation / gradients through csrc/bnorm.hip
+    FUSE_ACT = True              # bn_act(): residual add + ReLU inside the normalisation passes
 
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
         super().__init__()
-        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
-                                 track_running_stats=track_running_stats)
+        self.bn = _TickedBatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                     track_running_stats=track_running_stats)
+
+    def _tick(self):
+        bn = self.bn
+        if bn.track_running_stats and bn._buffers.get("num_batches_tracked") is not None:
+            bn.__dict__["_pending_ticks"] = bn.__dict__.get("_pending_ticks", 0) + 1
 
     def forward(self, x):
         f, bn = x.F, self.bn
         if self.NATIVE_TRAIN and bn.training and f.is_cuda and bn.momentum is not None and f.dtype in _DT and _rows_ok(f) \
                 and (bn.weight is None or bn.weight.dtype == torch.float32):
-            if bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+            self._tick()
             rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
             return x.replace_feature(_BatchNormTrainFn.apply(f, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum))
         # torch's batch-norm kernels take bf16/f16 slabs with fp32 parameters and statistics directly (identical

@@ -5,6 +5,9 @@
 // no atomics, so statistics and gradients are the same on every run.
 //   forward : partial (sum x, sum x^2) -> mean, biased var, invstd, running-stat update -> y = (x - mean) invstd w + b
 //   backward: partial (sum dy, sum dy (x - mean)) -> dbias, dweight, dx = w invstd (dy - mean(dy) - xhat mean(dy xhat))
+// The block tail of the network (Mink.py:293-350: conv -> bn -> relu, conv -> bn -> += residual -> relu) rides along: the
+// forward apply pass adds the residual and clamps, the backward passes mask dy with (y > 0) while they read it and hand the
+// masked gradient to the residual branch -- the ReLU / add passes over the slab and their launches disappear.
 #include "pbn_common.h"
 
 #include <hip/hip_bf16.h>
@@ -14,7 +17,7 @@ namespace pbn {
 namespace {
 
 constexpr int BN_TPB = 256;
-constexpr int BN_MAX_BLOCKS = 256;
+constexpr int BN_MAX_BLOCKS = 1024;
 
 template <typename T> struct Vec;
 template <> struct Vec<float> { static constexpr int W = 4; };
@@ -77,6 +80,7 @@ __device__ __forceinline__ Span span_of(int n, int vpr) {
 //   forward : A = x, B = x^2;   backward: A = dy, B = dy * (x - mean[c])
 template <typename T, bool BWD>
 __global__ __launch_bounds__(BN_TPB) void k_bn_partial(const T* __restrict__ x, int ld_x, const T* __restrict__ dy, int ld_dy,
+                                                      const T* __restrict__ ymask, int ld_y,
                                                       int n, int c, const float* __restrict__ mean, float* __restrict__ partial,
                                                       float* __restrict__ shift_out) {
     constexpr int W = Vec<T>::W;
@@ -102,6 +106,12 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_partial(const T* __restrict__ x, 
             if (BWD) {
                 float gv[W];
                 unpack(*reinterpret_cast<const uint4*>(dy + (size_t)row * ld_dy + s.cv * W), gv, (T*)nullptr);
+                if (ymask) {   // fused ReLU: the gradient only flows where the block's output was positive
+                    float yv[W];
+                    unpack(*reinterpret_cast<const uint4*>(ymask + (size_t)row * ld_y + s.cv * W), yv, (T*)nullptr);
+#pragma unroll
+                    for (int i = 0; i < W; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
+                }
 #pragma unroll
                 for (int i = 0; i < W; ++i) { a[i] += gv[i]; b[i] = fmaf(gv[i], xv[i] - mu[i], b[i]); }
             } else {
@@ -171,12 +181,15 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_bwd_final(const float* __restrict
     coef[c + ch] = (float)(s2 * is * is / n);           // multiplies (x - mean)
 }
 
-// forward apply: y = (x - mean) * (invstd * w) + b ; backward apply: dx = (dy - coef0 - (x - mean) * coef1) * (invstd * w)
+// forward apply: y = act((x - mean) * (invstd * w) + b [+ residual]) ; backward apply: g = dy masked by (y > 0),
+// dx = (g - coef0 - (x - mean) * coef1) * (invstd * w), residual gradient = g
 template <typename T, bool BWD>
 __global__ __launch_bounds__(BN_TPB) void k_bn_apply(const T* __restrict__ x, int ld_x, const T* __restrict__ dy, int ld_dy, int n,
                                                     int c, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                     const float* __restrict__ weight, const float* __restrict__ bias,
-                                                    const float* __restrict__ coef, T* __restrict__ out, int ld_out) {
+                                                    const float* __restrict__ coef, T* __restrict__ out, int ld_out,
+                                                    const T* __restrict__ aux, int ld_aux, int relu, T* __restrict__ dres,
+                                                    int ld_dres) {
     constexpr int W = Vec<T>::W;
     const int vpr = c / W;
     const long long e = (long long)blockIdx.x * BN_TPB + threadIdx.x;
@@ -187,6 +200,13 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_apply(const T* __restrict__ x, in
     if (BWD) {
         float gv[W];
         unpack(*reinterpret_cast<const uint4*>(dy + (size_t)row * ld_dy + cv * W), gv, (T*)nullptr);
+        if (aux) {   // aux = the forward output y: ReLU mask
+            float yv[W];
+            unpack(*reinterpret_cast<const uint4*>(aux + (size_t)row * ld_aux + cv * W), yv, (T*)nullptr);
+#pragma unroll
+            for (int i = 0; i < W; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
+        }
+        if (dres) *reinterpret_cast<uint4*>(dres + (size_t)row * ld_dres + cv * W) = pack(gv, (T*)nullptr);
 #pragma unroll
         for (int i = 0; i < W; ++i) {
             const int ch = cv * W + i;
@@ -200,12 +220,22 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_apply(const T* __restrict__ x, in
             const float scale = invstd[ch] * (weight ? weight[ch] : 1.f);
             o[i] = fmaf(xv[i] - mean[ch], scale, bias ? bias[ch] : 0.f);
         }
+        if (aux) {   // aux = the residual branch
+            float rv[W];
+            unpack(*reinterpret_cast<const uint4*>(aux + (size_t)row * ld_aux + cv * W), rv, (T*)nullptr);
+#pragma unroll
+            for (int i = 0; i < W; ++i) o[i] += rv[i];
+        }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < W; ++i) o[i] = fmaxf(o[i], 0.f);
+        }
     }
     *reinterpret_cast<uint4*>(out + (size_t)row * ld_out + cv * W) = pack(o, (T*)nullptr);
 }
 
 int blocks_for(int n) {
-    int b = (n + 511) / 512;
+    int b = (n + 127) / 128;
     return b < 1 ? 1 : (b > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : b);
 }
 
@@ -217,37 +247,44 @@ bool layout_ok(const void* p, int ld, int c) {
 
 template <typename T>
 int forward_t(const void* x, int ld_x, int n, int c, const float* weight, const float* bias, float eps, float momentum,
-              float* running_mean, float* running_var, void* y, int ld_y, float* save_mean, float* save_invstd, float* ws,
-              hipStream_t stream) {
-    if (!layout_ok<T>(x, ld_x, c) || !layout_ok<T>(y, ld_y, c)) return PBN_ERR_UNSUPPORTED;
+              float* running_mean, float* running_var, const void* residual, int ld_res, int relu, void* y, int ld_y,
+              float* save_mean, float* save_invstd, float* ws, hipStream_t stream) {
+    if (!layout_ok<T>(x, ld_x, c) || !layout_ok<T>(y, ld_y, c) || (residual && !layout_ok<T>(residual, ld_res, c)))
+        return PBN_ERR_UNSUPPORTED;
     constexpr int W = Vec<T>::W;
     const int blocks = blocks_for(n);
     hipLaunchKernelGGL((k_bn_partial<T, false>), dim3(blocks), dim3(BN_TPB), BN_TPB * 2 * W * sizeof(float), stream, (const T*)x,
-                       ld_x, (const T*)nullptr, 0, n, c, (const float*)nullptr, ws, ws + (size_t)BN_MAX_BLOCKS * 2 * c);
+                       ld_x, (const T*)nullptr, 0, (const T*)nullptr, 0, n, c, (const float*)nullptr, ws,
+                       ws + (size_t)BN_MAX_BLOCKS * 2 * c);
     hipLaunchKernelGGL(k_bn_stats_final, dim3(cdiv(c, BN_TPB / 64)), dim3(BN_TPB), 0, stream, ws,
                        ws + (size_t)BN_MAX_BLOCKS * 2 * c, blocks, n, c, eps, momentum,
                        running_mean, running_var, save_mean, save_invstd);
     const long long total = (long long)n * (c / W);
     hipLaunchKernelGGL((k_bn_apply<T, false>), dim3(cdiv(total, BN_TPB)), dim3(BN_TPB), 0, stream, (const T*)x, ld_x,
-                       (const T*)nullptr, 0, n, c, save_mean, save_invstd, weight, bias, (const float*)nullptr, (T*)y, ld_y);
+                       (const T*)nullptr, 0, n, c, save_mean, save_invstd, weight, bias, (const float*)nullptr, (T*)y, ld_y,
+                       (const T*)residual, ld_res, relu, (T*)nullptr, 0);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
 
 template <typename T>
-int backward_t(const void* x, int ld_x, const void* dy, int ld_dy, int n, int c, const float* weight, const float* save_mean,
-               const float* save_invstd, void* dx, int ld_dx, float* dweight, float* dbias, float* ws, hipStream_t stream) {
-    if (!layout_ok<T>(x, ld_x, c) || !layout_ok<T>(dy, ld_dy, c) || !layout_ok<T>(dx, ld_dx, c)) return PBN_ERR_UNSUPPORTED;
+int backward_t(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, int n, int c, const float* weight,
+               const float* save_mean, const float* save_invstd, void* dx, int ld_dx, void* dres, int ld_dres, float* dweight,
+               float* dbias, float* ws, hipStream_t stream) {
+    if (!layout_ok<T>(x, ld_x, c) || !layout_ok<T>(dy, ld_dy, c) || !layout_ok<T>(dx, ld_dx, c) ||
+        (y && !layout_ok<T>(y, ld_y, c)) || (dres && !layout_ok<T>(dres, ld_dres, c)))
+        return PBN_ERR_UNSUPPORTED;
     constexpr int W = Vec<T>::W;
     const int blocks = blocks_for(n);
     float* coef = ws + (size_t)BN_MAX_BLOCKS * 2 * c;
     hipLaunchKernelGGL((k_bn_partial<T, true>), dim3(blocks), dim3(BN_TPB), BN_TPB * 2 * W * sizeof(float), stream, (const T*)x,
-                       ld_x, (const T*)dy, ld_dy, n, c, save_mean, ws, (float*)nullptr);
+                       ld_x, (const T*)dy, ld_dy, (const T*)y, ld_y, n, c, save_mean, ws, (float*)nullptr);
     hipLaunchKernelGGL(k_bn_bwd_final, dim3(cdiv(c, BN_TPB / 64)), dim3(BN_TPB), 0, stream, ws, blocks, n, c, save_invstd, dweight,
                        dbias, coef);
     const long long total = (long long)n * (c / W);
     hipLaunchKernelGGL((k_bn_apply<T, true>), dim3(cdiv(total, BN_TPB)), dim3(BN_TPB), 0, stream, (const T*)x, ld_x,
-                       (const T*)dy, ld_dy, n, c, save_mean, save_invstd, weight, (const float*)nullptr, coef, (T*)dx, ld_dx);
+                       (const T*)dy, ld_dy, n, c, save_mean, save_invstd, weight, (const float*)nullptr, coef, (T*)dx, ld_dx,
+                       (const T*)y, ld_y, 0, (T*)dres, ld_dres);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
@@ -261,21 +298,49 @@ extern "C" size_t pbn_bn_workspace_bytes(int channels) {
     return channels > 0 ? sizeof(float) * ((size_t)BN_MAX_BLOCKS * 2 * channels + 2 * (size_t)channels) : 0;
 }
 
-extern "C" int pbn_bn_train_forward(const void* x, int ld_x, int n, int channels, int dtype, const float* weight, const float* bias,
-                                    float eps, float momentum, float* running_mean, float* running_var, void* y, int ld_y,
-                                    float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes,
-                                    pbn_stream_t stream_) {
+extern "C" int pbn_bn_act_train_forward(const void* x, int ld_x, int n, int channels, int dtype, const float* weight,
+                                        const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                                        const void* residual, int ld_res, int relu, void* y, int ld_y, float* save_mean,
+                                        float* save_invstd, void* workspace, size_t workspace_bytes, pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 1 || channels < 1 || !save_mean || !save_invstd) return PBN_ERR_ARG;
     if (!workspace || workspace_bytes < pbn_bn_workspace_bytes(channels) || ((uintptr_t)workspace & 15)) return PBN_ERR_WORKSPACE;
     float* ws = (float*)workspace;
     switch (dtype) {
-        case PBN_F32: return forward_t<float>(x, ld_x, n, channels, weight, bias, eps, momentum, running_mean, running_var, y,
-                                              ld_y, save_mean, save_invstd, ws, stream);
+        case PBN_F32: return forward_t<float>(x, ld_x, n, channels, weight, bias, eps, momentum, running_mean, running_var,
+                                              residual, ld_res, relu, y, ld_y, save_mean, save_invstd, ws, stream);
         case PBN_BF16: return forward_t<__hip_bfloat16>(x, ld_x, n, channels, weight, bias, eps, momentum, running_mean,
-                                                        running_var, y, ld_y, save_mean, save_invstd, ws, stream);
-        case PBN_F16: return forward_t<__half>(x, ld_x, n, channels, weight, bias, eps, momentum, running_mean, running_var, y,
-                                               ld_y, save_mean, save_invstd, ws, stream);
+                                                        running_var, residual, ld_res, relu, y, ld_y, save_mean, save_invstd, ws,
+                                                        stream);
+        case PBN_F16: return forward_t<__half>(x, ld_x, n, channels, weight, bias, eps, momentum, running_mean, running_var,
+                                               residual, ld_res, relu, y, ld_y, save_mean, save_invstd, ws, stream);
+        default: return PBN_ERR_ARG;
+    }
+}
+
+extern "C" int pbn_bn_train_forward(const void* x, int ld_x, int n, int channels, int dtype, const float* weight, const float* bias,
+                                    float eps, float momentum, float* running_mean, float* running_var, void* y, int ld_y,
+                                    float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes,
+                                    pbn_stream_t stream_) {
+    return pbn_bn_act_train_forward(x, ld_x, n, channels, dtype, weight, bias, eps, momentum, running_mean, running_var, nullptr, 0,
+                                    0, y, ld_y, save_mean, save_invstd, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int pbn_bn_act_train_backward(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, int n,
+                                         int channels, int dtype, const float* weight, const float* save_mean,
+                                         const float* save_invstd, void* dx, int ld_dx, void* dres, int ld_dres, float* dweight,
+                                         float* dbias, void* workspace, size_t workspace_bytes, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 1 || channels < 1 || !save_mean || !save_invstd) return PBN_ERR_ARG;
+    if (!workspace || workspace_bytes < pbn_bn_workspace_bytes(channels) || ((uintptr_t)workspace & 15)) return PBN_ERR_WORKSPACE;
+    float* ws = (float*)workspace;
+    switch (dtype) {
+        case PBN_F32: return backward_t<float>(x, ld_x, dy, ld_dy, y, ld_y, n, channels, weight, save_mean, save_invstd, dx, ld_dx,
+                                               dres, ld_dres, dweight, dbias, ws, stream);
+        case PBN_BF16: return backward_t<__hip_bfloat16>(x, ld_x, dy, ld_dy, y, ld_y, n, channels, weight, save_mean, save_invstd,
+                                                         dx, ld_dx, dres, ld_dres, dweight, dbias, ws, stream);
+        case PBN_F16: return backward_t<__half>(x, ld_x, dy, ld_dy, y, ld_y, n, channels, weight, save_mean, save_invstd, dx, ld_dx,
+                                                dres, ld_dres, dweight, dbias, ws, stream);
         default: return PBN_ERR_ARG;
     }
 }
@@ -283,17 +348,6 @@ extern "C" int pbn_bn_train_forward(const void* x, int ld_x, int n, int channels
 extern "C" int pbn_bn_train_backward(const void* x, int ld_x, const void* dy, int ld_dy, int n, int channels, int dtype,
                                      const float* weight, const float* save_mean, const float* save_invstd, void* dx, int ld_dx,
                                      float* dweight, float* dbias, void* workspace, size_t workspace_bytes, pbn_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (n < 1 || channels < 1 || !save_mean || !save_invstd) return PBN_ERR_ARG;
-    if (!workspace || workspace_bytes < pbn_bn_workspace_bytes(channels) || ((uintptr_t)workspace & 15)) return PBN_ERR_WORKSPACE;
-    float* ws = (float*)workspace;
-    switch (dtype) {
-        case PBN_F32: return backward_t<float>(x, ld_x, dy, ld_dy, n, channels, weight, save_mean, save_invstd, dx, ld_dx, dweight,
-                                               dbias, ws, stream);
-        case PBN_BF16: return backward_t<__hip_bfloat16>(x, ld_x, dy, ld_dy, n, channels, weight, save_mean, save_invstd, dx,
-                                                         ld_dx, dweight, dbias, ws, stream);
-        case PBN_F16: return backward_t<__half>(x, ld_x, dy, ld_dy, n, channels, weight, save_mean, save_invstd, dx, ld_dx,
-                                                dweight, dbias, ws, stream);
-        default: return PBN_ERR_ARG;
-    }
+    return pbn_bn_act_train_backward(x, ld_x, dy, ld_dy, nullptr, 0, n, channels, dtype, weight, save_mean, save_invstd, dx, ld_dx,
+                                     nullptr, 0, dweight, dbias, workspace, workspace_bytes, stream_);
 }

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--comm-dtype", default="f32", choices=["bf16", "f32"], help="gradient dtype on the wire")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce after backward instead of from gradient hooks")
+    ap.add_argument("--phases", action="store_true", help="also run 5 steps with a synchronisation after every phase and print the split")
     ap.add_argument("--small", action="store_true", help="a 20 k-point room instead of a ScanNet-sized scene (smoke runs)")
     args = ap.parse_args()
     import torch.distributed as dist
@@ -57,6 +58,33 @@ def main():
                                  overlap=not args.no_overlap)
     t_comm = [0.0]
 
+    phases = {}
+
+    def mark(name, t_prev, sync):
+        if sync:
+            torch.cuda.synchronize()
+        t = time.perf_counter()
+        phases[name] = phases.get(name, 0.0) + (t - t_prev)
+        return t
+
+    def step_phases():
+        """The same step with a device synchronisation after every phase (--phases): where the host waits for the GPU
+        and where the GPU waits for the host.  Not the timed configuration."""
+        t = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss, pred, visual, meter = model_fn(batch, model, 1, cfg, "train")
+        t = mark("forward_host", t, False)
+        t = mark("forward_gpu_tail", t, True)
+        loss.backward()
+        t = mark("backward_host", t, False)
+        t = mark("backward_gpu_tail", t, True)
+        reducer.finish()
+        t = mark("allreduce", t, True)
+        opt.step()
+        t = mark("optimizer_host", t, False)
+        t = mark("optimizer_gpu_tail", t, True)
+        return loss
+
     def step():
         opt.zero_grad(set_to_none=True)
         loss, pred, visual, meter = model_fn(batch, model, 1, cfg, "train")
@@ -77,6 +105,12 @@ def main():
         loss = step()
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if args.phases:
+        for _ in range(5):
+            step_phases()
+        if rank == 0:
+            print("phases ms/step (synchronised after each): " + ", ".join("%s %.2f" % (k, v / 5 * 1e3) for k, v in phases.items()),
+                  file=sys.stderr)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     pd.sync_buffers(model)                                          # what precedes validation / checkpoint_save
     lossv = torch.tensor([float(loss)], device=dev)
