@@ -312,6 +312,8 @@ int launch_by_cfg(const ConvArgs& a, int cfg, hipStream_t stream) {
         case 1201: return launch_cfg<T, 2, 1, 8, true>(a, stream);
         case 1202: return launch_cfg<T, 2, 2, 8, true>(a, stream);
         case 1204: return launch_cfg<T, 2, 4, 8, true>(a, stream);
+        case 1208: return launch_cfg<T, 2, 8, 8, true>(a, stream);
+        case 1408: return launch_cfg<T, 4, 8, 8, true>(a, stream);
         default: return PBN_ERR_UNSUPPORTED;
     }
 }
@@ -322,8 +324,6 @@ int launch_by_cfg(const ConvArgs& a, int cfg, hipStream_t stream) {
 int pick_cfg(const ConvArgs& a) {
     const int ntt = a.ntiles_total;
     const long long rows = a.n_out;
-    // K-split candidates from the widest tile down; the first one that gives the chip one round of workgroups wins
-    // (fitted on scripts/probe_wave.py: 1202 on the 791-row level, 1204 / 1404 on the 3.5 k- and 14.7 k-row levels)
     // stem-like layers (a 16/32-byte input row, K = 125): 32 rows x 32 channels per workgroup measured best at every size
     // (146 k rows: 44.8 us against 68.1 for 64 rows and 72.6 for the workgroup-tile kernel)
     if (a.vpo <= 2 && a.K >= 64 && ntt % 2 == 0) return 1202;
@@ -364,6 +364,10 @@ int launch_wave(const ConvArgs& a, int dtype, int force_cfg, hipStream_t stream)
 }
 
 // PBN_CONV_FAMILY: 0 = workgroup-tile kernels only (round 1), 1 = wave kernels only, 2 (default) = by size of the op.
+// Several scenes in flight (scripts/probe_wave.py with PBN_PROBE_STREAMS=4) would pick wider channel tiles on the same
+// layers (1408: L3 256->256 19.6 us against 26.3 for 1404; 43.6 against 33.6 alone) -- in the real pipeline, where the
+// other streams run OTHER layers, a process-wide switch to those tiles measured 2-3 % slower (274-278 against 283-285
+// scenes/s), so the choice below stays the one-scene one.
 // Measured crossover (scripts/probe_wave.py, HIP-graph replay): the K-split wave kernel is level with or ahead of the
 // workgroup-tile kernel + its split-K reduce launch up to ~6e9 dense MACs (rows x K x C_in x C_out) on levels below 20 k
 // rows, and behind it above (L3 384->256, L2 128->128) and on every wide level.

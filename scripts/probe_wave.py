@@ -13,6 +13,7 @@ cm = ME.CoordinateManager(torch.from_numpy(batch["xyz_voxel"]).to(dev))
 pyr = cm.sorted().pyramid
 torch.manual_seed(0)
 REP = 20
+STREAMS = int(os.environ.get("PBN_PROBE_STREAMS", "1"))      # > 1: the same layer on that many streams at once (throughput mode)
 CFGS = [int(c) for c in os.environ.get("PBN_PROBE_CFGS", "32,401,402,404,406,408,204,206,208,1401,1402,1404,1201,1202,1204").split(",")]
 
 
@@ -33,6 +34,29 @@ def run(level, cin, cout, k=3):
         except RuntimeError:
             continue
         torch.cuda.synchronize()
+        if STREAMS > 1:
+            streams = [torch.cuda.Stream() for _ in range(STREAMS)]
+            outs = [torch.empty_like(out) for _ in range(STREAMS)]
+            graphs = []
+            for st, o in zip(streams, outs):
+                with torch.cuda.stream(st):
+                    for _ in range(2):
+                        spconv_forward(x, nbr, n, packed, rows_per_wave=cfg, out=o)
+                torch.cuda.synchronize()
+                gq = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gq, stream=st):
+                    for _ in range(REP):
+                        spconv_forward(x, nbr, n, packed, rows_per_wave=cfg, out=o)
+                graphs.append(gq)
+            def go():
+                for st, gq in zip(streams, graphs):
+                    with torch.cuda.stream(st):
+                        gq.replay()
+            go(); torch.cuda.synchronize()
+            import time
+            t0 = time.perf_counter(); go(); go(); torch.cuda.synchronize(); t1 = time.perf_counter()
+            res.append((cfg, (t1 - t0) / (2 * REP * STREAMS) * 1e6))
+            continue
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for _ in range(REP):
