@@ -214,6 +214,18 @@ int pbn_gather_pad_rows(const void* in, int ld_in_bytes, int row_bytes, const in
 int pbn_pack_weight(const float* src, int n_offsets, int dim_a, int dim_b, int flip, int transpose, int dtype,
                     int vecs_per_offset, int n_steps, int cout_padded, void* out, pbn_stream_t stream);
 
+/* pbn_pack_weights_batch -- the same packing for many layers in ONE launch (a training step repacks every layer's forward
+ * and input-gradient weights once): `jobs` is a DEVICE array of n_jobs descriptors with pbn_pack_weight's arguments
+ * (cin / cout / cin_p = vecs_per_offset * elements-per-16-bytes spelled out), max_vectors = the largest job's
+ * n_steps * cout_p/16 * 64 (sizes the grid).  All jobs share `dtype`. */
+typedef struct pbn_pack_job {
+    const float* src;      /* fp32 master [n_offsets, dim_a, dim_b] */
+    void* out;             /* n_steps * cout_p/16 * 1024 bytes */
+    int32_t n_offsets, dim_a, dim_b, flip, transpose, cin, cout, cin_p, cout_p, n_steps;
+    int32_t reserved[2];
+} pbn_pack_job;
+int pbn_pack_weights_batch(const pbn_pack_job* jobs, int n_jobs, int max_vectors, int dtype, pbn_stream_t stream);
+
 /* pbn_gather_rulebook_rows -- the gathered operand of the weight gradient (training, BASELINE configs[2]):
  * out[v, j, 0:row_bytes] = in[nbr[v, k0 + j], 0:row_bytes] for j < kc, zeros where nbr is -1; out is dense
  * [n, kc, row_bytes].  dW[k0:k0+kc] is then one dense contraction of this slab with the output gradient. */

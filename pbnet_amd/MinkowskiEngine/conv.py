@@ -6,6 +6,8 @@ Mirrors the constructor signatures and parameter names the reference uses from M
 """
 import math
 import os
+import threading
+import weakref
 
 import numpy as np
 import torch
@@ -61,28 +63,111 @@ def pack_weight(kernel, dtype, flip=False, transpose=False):
     return w, vpo, n_steps, cout_p
 
 
-class _PackCache(object):
-    """Per-module cache of packed weights keyed by (dtype, parameter version)."""
+_JOB = np.dtype([("src", "<u8"), ("out", "<u8"), ("n_offsets", "<i4"), ("dim_a", "<i4"), ("dim_b", "<i4"), ("flip", "<i4"),
+                 ("transpose", "<i4"), ("cin", "<i4"), ("cout", "<i4"), ("cin_p", "<i4"), ("cout_p", "<i4"), ("n_steps", "<i4"),
+                 ("reserved", "<i4", (2,))])          # include/pbnet_hip.h: pbn_pack_job (64 bytes)
+_PACK_MODULES = weakref.WeakSet()                      # every live convolution module (MinkowskiConvolutionBase)
+
+
+def _pack_dims(k, a, b, dtype, transpose):
+    cin, cout = (b, a) if transpose else (a, b)
+    e = _ELEMS[dtype]
+    vpo = _vpo(cin, dtype)
+    cout_p = (cout + 15) // 16 * 16
+    return cin, cout, vpo, vpo * e, cout_p, (k * vpo + 3) // 4
+
+
+class _BatchPacker(object):
+    """Weight packing for ALL convolution layers in one launch (pbn_pack_weights_batch): a training step changes every
+    kernel, so the first layer that finds its packed weights stale repacks the forward form of every stale layer on
+    its device -- and, with autograd on, the input-gradient form (mirrored offsets, swapped channel roles) as well.
+    Output buffers are reused while their size is unchanged, the device job table while the set of jobs is."""
 
     def __init__(self):
+        self.lock = threading.Lock()
+        self.tables = {}          # (device, dtype) -> (signature, device table, max_vectors, jobs)
+
+    def refresh(self, device, dtype, with_dgrad):
+        with self.lock:
+            jobs = []
+            for m in list(_PACK_MODULES):
+                w = m.kernel
+                if w.device != device or w.dtype != torch.float32 or not w.is_contiguous():
+                    continue
+                key = (dtype, w._version, w.data_ptr(), w.device)
+                forms = (("f", False, False), ("d", bool(m._dgrad_flip), True)) if (with_dgrad and w.requires_grad) else \
+                    (("f", False, False),)
+                for form, flip, transpose in forms:
+                    hit = m._cache.store.get((form, dtype))
+                    if hit is not None and hit[0] == key:
+                        continue
+                    k3 = w if w.dim() == 3 else w.unsqueeze(0)
+                    k, a, b = int(k3.shape[0]), int(k3.shape[1]), int(k3.shape[2])
+                    cin, cout, vpo, cin_p, cout_p, n_steps = _pack_dims(k, a, b, dtype, transpose)
+                    old = None if hit is None else hit[1][0]
+                    shape = (n_steps, cout_p // 16, 64, _ELEMS[dtype])
+                    out = old if (old is not None and tuple(old.shape) == shape and old.dtype == dtype) else \
+                        torch.empty(*shape, dtype=dtype, device=device)
+                    jobs.append((m, form, key, (out, vpo, n_steps, cout_p),
+                                 (w.data_ptr(), out.data_ptr(), k, a, b, int(flip), int(transpose), cin, cout, cin_p, cout_p, n_steps)))
+            if not jobs:
+                return
+            sig = tuple(j[4] for j in jobs)
+            cached = self.tables.get((device, dtype))
+            if cached is None or cached[0] != sig:
+                host = np.zeros(len(jobs), dtype=_JOB)
+                for i, j in enumerate(jobs):
+                    host[i] = j[4] + ((0, 0),)
+                table = torch.from_numpy(host.view(np.uint8).reshape(-1)).to(device)
+                max_vec = max(j[4][11] * (j[4][10] // 16) * 64 for j in jobs)
+                cached = (sig, table, max_vec)
+                self.tables[(device, dtype)] = cached
+            N.check(N.lib().pbn_pack_weights_batch(N.c_vp(cached[1].data_ptr()), len(jobs), int(cached[2]), _DT[dtype],
+                                                   N.current_stream()), "pbn_pack_weights_batch")
+            for m, form, key, packed, _ in jobs:
+                m._cache.store[(form, dtype)] = (key, packed)
+
+
+_BATCH = _BatchPacker()
+
+
+class _PackCache(object):
+    """Per-module cache of packed weights keyed by (form, dtype) -> (parameter version key, packed)."""
+
+    def __init__(self, owner=None):
         self.store = {}
+        self.owner = None if owner is None else weakref.ref(owner)
+
+    def _lookup(self, form, kernel, dtype, flip, transpose):
+        key = (dtype, kernel._version, kernel.data_ptr(), kernel.device)
+        hit = self.store.get((form, dtype))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        owner = None if self.owner is None else self.owner()
+        if owner is not None and kernel.is_cuda and kernel.data_ptr() == owner.kernel.data_ptr():
+            _BATCH.refresh(kernel.device, dtype, torch.is_grad_enabled() or form == "d")
+            hit = self.store.get((form, dtype))
+            if hit is not None and hit[0] == key:
+                return hit[1]
+        k3 = kernel if kernel.dim() == 3 else kernel.unsqueeze(0)
+        hit = (key, pack_weight(k3.detach(), dtype, flip=flip, transpose=transpose))
+        self.store[(form, dtype)] = hit
+        return hit[1]
 
     def get(self, kernel, dtype):
-        key = (dtype, kernel._version, kernel.data_ptr(), kernel.device)
-        hit = self.store.get(dtype)
-        if hit is None or hit[0] != key:
-            k3 = kernel if kernel.dim() == 3 else kernel.unsqueeze(0)
-            hit = (key, pack_weight(k3, dtype))
-            self.store[dtype] = hit
-        return hit[1]
+        return self._lookup("f", kernel, dtype, False, False)
+
+    def get_dgrad(self, kernel, dtype, flip):
+        """Input-gradient weights of a forward kernel: offsets mirrored when `flip`, channel roles swapped."""
+        return self._lookup("d", kernel, dtype, bool(flip), True)
 
     def get_linear(self, weight, dtype):
         """nn.Linear weight [out, in] -> packed [1, in, out]."""
         key = (dtype, weight._version, weight.data_ptr(), weight.device)
-        hit = self.store.get(dtype)
+        hit = self.store.get(("l", dtype))
         if hit is None or hit[0] != key:
             hit = (key, pack_weight(weight.detach().unsqueeze(0), dtype, transpose=True))
-            self.store[dtype] = hit
+            self.store[("l", dtype)] = hit
         return hit[1]
 
 
@@ -229,7 +314,7 @@ class _ConvFn(torch.autograd.Function):
         out = spconv_forward(feats, nbr, n_out, packed, shift=shift)
         cout = kernel.shape[-1]
         ctx.save_for_backward(feats, kernel)
-        ctx.nbr, ctx.dgrad_nbr, ctx.flip, ctx.has_bias = nbr, dgrad_nbr, flip, bias is not None
+        ctx.nbr, ctx.dgrad_nbr, ctx.flip, ctx.has_bias, ctx.cache = nbr, dgrad_nbr, flip, bias is not None, cache
         return out if out.shape[1] == cout else out[:, :cout]
 
     @staticmethod
@@ -240,7 +325,7 @@ class _ConvFn(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         grad_feats = grad_kernel = grad_bias = None
         if ctx.needs_input_grad[0]:
-            packed = pack_weight(k3.detach(), grad_out.dtype, flip=bool(ctx.flip), transpose=True)   # [K, Cout, Cin]
+            packed = ctx.cache.get_dgrad(kernel, grad_out.dtype, ctx.flip)                           # [K, Cout, Cin]
             gi = spconv_forward(grad_out, ctx.dgrad_nbr, feats.shape[0], packed)
             grad_feats = gi if gi.shape[1] == feats.shape[1] else gi[:, :feats.shape[1]]
         if ctx.needs_input_grad[1]:
@@ -263,7 +348,10 @@ class MinkowskiConvolutionBase(nn.Module):
         shape = (in_channels, out_channels) if self.use_mm else (self.kernel_volume, in_channels, out_channels)
         self.kernel = nn.Parameter(torch.empty(*shape))
         self.bias = nn.Parameter(torch.empty(1, out_channels)) if bias else None
-        self._cache = _PackCache()
+        self._cache = _PackCache(self)
+        # the offsets of the input-gradient weights are mirrored for centred cubes only (see _map)
+        self._dgrad_flip = (not is_transpose) and self.stride == 1 and self.kernel_size > 1 and self.kernel_size % 2 == 1
+        _PACK_MODULES.add(self)
         self.reset_parameters()
 
     def reset_parameters(self):

@@ -110,6 +110,7 @@ SIGNATURES = {
     "pbn_rulebook_pair_counts": (c_int, [c_i32p, c_int, c_int, c_i32p, c_i32p, c_vp]),
     "pbn_rulebook_pair_fill": (c_int, [c_i32p, c_int, c_int, c_i32p, c_i32p, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "pbn_gather_rulebook_rows": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "pbn_pack_weights_batch": (c_int, [c_vp, c_int, c_int, c_int, c_vp]),
     "pbn_pack_weight": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "pbn_kernel_map_cube": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_coords_arena_bytes": (c_size, [c_int, c_int, ctypes.POINTER(CoordsLayout)]),

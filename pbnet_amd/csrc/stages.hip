@@ -411,14 +411,10 @@ __global__ __launch_bounds__(TPB) void k_gather_rulebook_rows(const unsigned* __
 // element (k, ci, co) of the convolution = src[flip ? K-1-k : k][ci][co], or [..][co][ci] when `transpose` (the dgrad
 // weights of a forward kernel).  One thread per packed element; E = elements per 16-byte vector.
 template <typename T>
-__global__ __launch_bounds__(TPB) void k_pack_weight(const float* __restrict__ src, int K, int A, int B, int flip,
-                                                    int transpose, int cin, int cout, int cin_p, int cout_p, int n_steps,
-                                                    T* __restrict__ out) {
+__device__ __forceinline__ void pack_weight_element(const float* __restrict__ src, int K, int A, int B, int flip, int transpose,
+                                                    int cin, int cout, int cin_p, int cout_p, long long e, T* __restrict__ out) {
     constexpr int E = 16 / (int)sizeof(T);
-    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
     const int ntt = cout_p / 16;
-    const long long total = (long long)n_steps * ntt * 64 * E;
-    if (e >= total) return;
     const int j = (int)(e % E);
     const int lane = (int)((e / E) % 64);
     const int tt = (int)((e / (E * 64)) % ntt);
@@ -433,6 +429,28 @@ __global__ __launch_bounds__(TPB) void k_pack_weight(const float* __restrict__ s
         v = transpose ? src[((size_t)ks * A + co) * B + ci] : src[((size_t)ks * A + ci) * B + co];
     }
     RowIO<T>::store(out + e, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void k_pack_weight(const float* __restrict__ src, int K, int A, int B, int flip,
+                                                    int transpose, int cin, int cout, int cin_p, int cout_p, int n_steps,
+                                                    T* __restrict__ out) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+    const long long total = (long long)n_steps * (cout_p / 16) * 64 * E;
+    if (e >= total) return;
+    pack_weight_element<T>(src, K, A, B, flip, transpose, cin, cout, cin_p, cout_p, e, out);
+}
+
+// every layer's weights (both the forward and the input-gradient form) in ONE launch: blockIdx.y = job of a device table
+template <typename T>
+__global__ __launch_bounds__(TPB) void k_pack_weights_batch(const pbn_pack_job* __restrict__ jobs) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const pbn_pack_job jb = jobs[blockIdx.y];
+    const long long total = (long long)jb.n_steps * (jb.cout_p / 16) * 64 * E;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB)
+        pack_weight_element<T>(jb.src, jb.n_offsets, jb.dim_a, jb.dim_b, jb.flip, jb.transpose, jb.cin, jb.cout, jb.cin_p,
+                               jb.cout_p, e, (T*)jb.out);
 }
 
 }  // namespace
@@ -853,6 +871,23 @@ extern "C" int pbn_pack_weight(const float* src, int n_offsets, int dim_a, int d
                            cin, cout, cin_p, cout_padded, n_steps, (__half*)out);
     else
         return PBN_ERR_ARG;
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_pack_weights_batch(const pbn_pack_job* jobs_dev, int n_jobs, int max_vectors, int dtype, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_jobs < 0 || max_vectors < 0) return PBN_ERR_ARG;
+    if (n_jobs == 0 || max_vectors == 0) return PBN_OK;
+    if (!jobs_dev || n_jobs > 65535) return PBN_ERR_ARG;
+    const int e = dtype == PBN_F32 ? 4 : 8;
+    long long bx = cdiv((long long)max_vectors * e, TPB);
+    if (bx > 512) bx = 512;
+    const dim3 grid((unsigned)bx, (unsigned)n_jobs);
+    if (dtype == PBN_F32) hipLaunchKernelGGL(k_pack_weights_batch<float>, grid, dim3(TPB), 0, stream, jobs_dev);
+    else if (dtype == PBN_BF16) hipLaunchKernelGGL(k_pack_weights_batch<__hip_bfloat16>, grid, dim3(TPB), 0, stream, jobs_dev);
+    else if (dtype == PBN_F16) hipLaunchKernelGGL(k_pack_weights_batch<__half>, grid, dim3(TPB), 0, stream, jobs_dev);
+    else return PBN_ERR_ARG;
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
