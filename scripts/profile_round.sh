@@ -5,6 +5,7 @@
 #   <tag>_inflight1_kernel_stats.csv   the same with one scene in flight
 #   <tag>_pmc_summary.json             HBM traffic per kernel family: two --pmc passes (FETCH_SIZE, WRITE_SIZE), own runs
 #   <tag>_sq_conv_summary.json         SQ counters (MFMA busy, waits) of the convolution kernels, own pass
+#   <tag>_train_step.json / <tag>_train_kernel_stats.csv   scripts/train_step.py (configs[2] on one rank) and its kernel table
 R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT unset)}
 TAG=${1:?usage: profile_round.sh <tag>}
 # bench.py sets this with os.environ.setdefault, but under rocprofv3 the profiler has initialised the runtime before Python
@@ -27,5 +28,9 @@ done
 python scripts/summarize_pmc.py /tmp/pmc_flat_FETCH_SIZE /tmp/pmc_flat_WRITE_SIZE $O/${TAG}_pmc_summary.json > $O/pmc_summary.log 2>&1; tail -3 $O/pmc_summary.log
 timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_sq -o sq -- python bench.py --no-extras --inflight 1 --steps 5 --warmup 2 --repeats 1 > $O/pmc_sq.log 2>&1
 python scripts/summarize_sq.py $(find /tmp/pmc_sq -name "sq_counter_collection.csv" | head -1) $(find /tmp/pmc_sq -name "sq_kernel_trace.csv" | head -1) $O/${TAG}_sq_conv_summary.json > $O/sq_summary.log 2>&1; tail -12 $O/sq_summary.log
+# the training step of configs[2]: its line and its kernel table
+timeout 300 python scripts/train_step.py --steps 8 --warmup 2 --phases > $O/${TAG}_train_step.json 2> $O/train_step.err; tail -1 $O/${TAG}_train_step.json | cut -c1-200; grep phases $O/train_step.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -- python scripts/train_step.py --steps 5 --warmup 1 > $O/ktt.log 2>&1
+cp $(find $O/ktt -name "*kernel_stats.csv" | head -1) $O/${TAG}_train_kernel_stats.csv; rm -rf $O/ktt
 find $O -name "*_kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; rm -rf $O/kt $O/kt1
 ls $O
