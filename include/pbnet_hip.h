@@ -275,11 +275,19 @@ int pbn_rulebook_pair_counts(const int32_t* nbr, int n, int n_offsets, int32_t* 
 int pbn_rulebook_pair_fill(const int32_t* nbr, int n, int n_offsets, const int32_t* table, const int32_t* seg_start, int seg,
                            int n_segments, int64_t* in_idx, int64_t* out_idx, int64_t* seg_offset, pbn_stream_t stream);
 
+/* pbn_rulebook_pair_fill_dev -- the same lists with NO host knowledge of the pair counts (no read-back between
+ * pbn_rulebook_pair_counts and the fill: a training step builds ~40 maps): seg_begin int32[n_offsets + 1] is computed on the
+ * device from `totals`, in_idx / out_idx / seg_offset must hold the worst case of n * n_offsets / segment + n_offsets
+ * segments, only the segments below seg_begin[n_offsets] are written (tails padded with -1) and may be read. */
+int pbn_rulebook_pair_fill_dev(const int32_t* nbr, int n, int n_offsets, const int32_t* table, const int32_t* totals,
+                               int segment, int32_t* seg_begin, int64_t* in_idx, int64_t* out_idx, int64_t* seg_offset,
+                               pbn_stream_t stream);
+
 /* Weight gradient of the sparse convolution on the matrix cores (csrc/wgrad.hip), ME's convolution backward w.r.t. the
  * kernel (reached from train.py:57 loss.backward()):  dw[k, ci, co] = sum over the pairs (i, o) of offset k of
  * x[i, ci] * g[o, co].  in_idx / out_idx / seg_begin: the lists of pbn_rulebook_pair_fill, seg_begin int32[K+1] = first
- * `segment`-pair segment of every offset; all three NULL = identity pairs (1x1 convolution / linear layer; n_offsets 1,
- * n_pairs_total rows).  x [*, ld_x], g [*, ld_g] of `dtype` (widened exactly), dw f32[K, cin, cout], any cin / cout.
+ * `segment`-pair segment of every offset, read on the DEVICE (with lists n_pairs_total only sizes the pair splits: an estimate
+ * will do); all three NULL = identity pairs (1x1 convolution / linear layer; n_offsets 1, n_pairs_total rows).  x [*, ld_x], g [*, ld_g] of `dtype` (widened exactly), dw f32[K, cin, cout], any cin / cout.
  * fp32 accumulation in a fixed order (deterministic).  workspace: pbn_spconv_wgrad_workspace_bytes (pair splits). */
 size_t pbn_spconv_wgrad_workspace_bytes(int n_offsets, int cin, int cout);
 int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g, int dtype, const int64_t* in_idx,

@@ -268,6 +268,37 @@ def rulebook_pairs(nbr, segment=WGRAD_PAIR_SEGMENT):
     return hit[:4]
 
 
+def rulebook_pairs_dev(nbr, segment=WGRAD_PAIR_SEGMENT):
+    """rulebook_pairs without the read-back: the lists are sized for the worst case (rows x offsets / segment + offsets
+    segments), the per-offset segment ranges are computed on the device (pbn_rulebook_pair_fill_dev) and only consumers
+    that read `seg_begin` on the device (pbn_spconv_wgrad) may use them.  -> (in_idx, out_idx, seg_begin, capacity)."""
+    hit = getattr(nbr, "_pbn_pairs_dev", None)
+    if hit is not None and hit[4] == segment:
+        return hit[:4]
+    N.require_cuda(nbr)
+    assert nbr.dtype == torch.int32 and nbr.is_contiguous()
+    lib = N.lib()
+    v, k = int(nbr.shape[0]), int(nbr.shape[1])
+    dev = nbr.device
+    table = torch.empty(max(lib.pbn_rulebook_pair_blocks(v), 1) * k, dtype=torch.int32, device=dev)
+    totals = torch.empty(k, dtype=torch.int32, device=dev)
+    st = N.current_stream()
+    N.check(lib.pbn_rulebook_pair_counts(N.ptr(nbr), v, k, N.ptr(table), N.ptr(totals), st), "pbn_rulebook_pair_counts")
+    cap = (v * k) // segment + k
+    in_idx = torch.empty(cap * segment, dtype=torch.int64, device=dev)
+    out_idx = torch.empty(cap * segment, dtype=torch.int64, device=dev)
+    seg_offset = torch.empty(cap, dtype=torch.int64, device=dev)
+    seg_begin = torch.empty(k + 1, dtype=torch.int32, device=dev)
+    N.check(lib.pbn_rulebook_pair_fill_dev(N.ptr(nbr), v, k, N.ptr(table), N.ptr(totals), segment, N.ptr(seg_begin),
+                                           N.ptr(in_idx), N.ptr(out_idx), N.ptr(seg_offset), st), "pbn_rulebook_pair_fill_dev")
+    hit = (in_idx, out_idx, seg_begin, cap, segment)
+    try:
+        nbr._pbn_pairs_dev = hit
+    except AttributeError:
+        pass
+    return hit[:4]
+
+
 _WGRAD_WS = StreamScratch()
 
 
@@ -285,9 +316,10 @@ def wgrad_native(feats, grad_out, nbr, cin, cout):
     else:
         assert nbr.is_contiguous()
         k = int(nbr.shape[1])
-        rulebook_pairs(nbr)
-        in_idx, out_idx, _, n_seg, segment, seg_begin = nbr._pbn_pairs
-        n_pairs = n_seg * segment
+        in_idx, out_idx, seg_begin, _ = rulebook_pairs_dev(nbr)      # no read-back: the segment ranges stay on the device
+        # the host only needs the pair count to choose the number of pair splits: a third of the table populated is the
+        # bench scene's stride-2..16 levels (12-16 of 27), stride 1 holds 7.6 of 27
+        n_pairs = max(WGRAD_PAIR_SEGMENT, (int(nbr.shape[0]) * k) // 3)
     dw = torch.empty(k, cin, cout, dtype=torch.float32, device=dev)
     ws = _WGRAD_WS.get(dev, int(lib.pbn_spconv_wgrad_workspace_bytes(k, cin, cout)))
     rc = lib.pbn_spconv_wgrad(N.c_vp(feats.data_ptr()), feats.stride(0), N.c_vp(grad_out.data_ptr()), grad_out.stride(0),

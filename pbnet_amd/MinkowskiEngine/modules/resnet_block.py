@@ -20,7 +20,14 @@ class BasicBlock(nn.Module):
         self.relu = MinkowskiReLU(inplace=True)
         self.downsample = downsample
 
+    FUSED_TRAIN = True          # native training path: the whole block as one autograd node (fused_train.basic_block)
+
     def forward(self, x):
+        if self.FUSED_TRAIN and self.training:
+            from ..fused_train import basic_block
+            y = basic_block(self, x)
+            if y is not None:
+                return y
         # the reference's block (conv -> bn -> relu -> conv -> bn -> += residual -> relu); bn_act runs each bn with its
         # tail as one pass when the native training path is on, and the separate modules otherwise
         residual = x

@@ -108,6 +108,7 @@ SIGNATURES = {
     "pbn_bn_act_train_backward": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p,
                                           c_vp, c_int, c_vp, c_int, c_f32p, c_f32p, c_vp, c_size, c_vp]),
     "pbn_rulebook_pair_counts": (c_int, [c_i32p, c_int, c_int, c_i32p, c_i32p, c_vp]),
+    "pbn_rulebook_pair_fill_dev": (c_int, [c_i32p, c_int, c_int, c_i32p, c_i32p, c_int, c_i32p, c_vp, c_vp, c_vp, c_vp]),
     "pbn_rulebook_pair_fill": (c_int, [c_i32p, c_int, c_int, c_i32p, c_i32p, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "pbn_gather_rulebook_rows": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "pbn_pack_weights_batch": (c_int, [c_vp, c_int, c_int, c_int, c_vp]),

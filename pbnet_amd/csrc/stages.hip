@@ -794,6 +794,35 @@ __global__ __launch_bounds__(TPB) void k_pair_fill(const int* __restrict__ nbr, 
         __syncthreads();
     }
 }
+
+// seg_begin[k] = segments of the offsets before k (one wave; K <= a few hundred)
+__global__ __launch_bounds__(64) void k_pair_segments(const int* __restrict__ totals, int K, int seg, int* __restrict__ seg_begin) {
+    const int lane = threadIdx.x;
+    int run = 0;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        const int v = k < K ? (totals[k] + seg - 1) / seg : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (k < K) seg_begin[k] = run + inc - v;
+        run += __shfl(inc, 63);
+    }
+    if (lane == 0) seg_begin[K] = run;
+}
+
+// -1 into the unused tail of every offset's last segment (at most seg - 1 slots per offset): no fill of the whole lists
+__global__ __launch_bounds__(TPB) void k_pair_pad(const int* __restrict__ totals, const int* __restrict__ seg_begin, int seg,
+                                                 long long* __restrict__ in_idx, long long* __restrict__ out_idx) {
+    const int k = blockIdx.x;
+    const int cnt = totals[k];
+    const long long base = (long long)seg_begin[k] * seg;
+    const int end = (seg_begin[k + 1] - seg_begin[k]) * seg;
+    for (int i = cnt + threadIdx.x; i < end; i += TPB) { in_idx[base + i] = -1; out_idx[base + i] = -1; }
+}
 }  // namespace
 }  // namespace pbn
 
@@ -828,6 +857,23 @@ extern "C" int pbn_rulebook_pair_fill(const int32_t* nbr, int n, int n_offsets, 
     if (!nbr || !table || !seg_start) return PBN_ERR_ARG;
     hipLaunchKernelGGL(k_pair_fill, dim3(pbn_rulebook_pair_blocks(n)), dim3(TPB), 0, stream, nbr, n, n_offsets, table, seg_start,
                        seg, (long long*)in_idx, (long long*)out_idx, (long long*)seg_offset);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
+extern "C" int pbn_rulebook_pair_fill_dev(const int32_t* nbr, int n, int n_offsets, const int32_t* table, const int32_t* totals,
+                                          int seg, int32_t* seg_begin, int64_t* in_idx, int64_t* out_idx, int64_t* seg_offset,
+                                          pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || n_offsets < 1 || seg < 1 || !totals || !seg_begin) return PBN_ERR_ARG;
+    hipLaunchKernelGGL(k_pair_segments, dim3(1), dim3(64), 0, stream, totals, n_offsets, seg, seg_begin);
+    if (n > 0) {
+        if (!nbr || !table || !in_idx || !out_idx || !seg_offset) return PBN_ERR_ARG;
+        hipLaunchKernelGGL(k_pair_fill, dim3(pbn_rulebook_pair_blocks(n)), dim3(TPB), 0, stream, nbr, n, n_offsets, table, seg_begin,
+                           seg, (long long*)in_idx, (long long*)out_idx, (long long*)seg_offset);
+        hipLaunchKernelGGL(k_pair_pad, dim3(n_offsets), dim3(TPB), 0, stream, totals, seg_begin, seg, (long long*)in_idx,
+                           (long long*)out_idx);
+    }
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }

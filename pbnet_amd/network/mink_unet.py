@@ -19,7 +19,7 @@ import torch.nn as nn
 from .. import MinkowskiEngine as ME
 from ..MinkowskiEngine.conv import spconv_forward, _pad_vec
 from ..MinkowskiEngine.modules.resnet_block import BasicBlock
-from ..MinkowskiEngine.nn import bn_act
+from ..MinkowskiEngine.fused_train import conv_bn_act
 from ..prof import section
 
 # arch -> (blocks per stage, planes)   (Mink.py:357-419; BasicBlock families only)
@@ -107,15 +107,15 @@ class MinkUNet(nn.Module):
 
     def _forward_modules(self, x):
         """Mink.py:291-354, module by module."""
-        out = bn_act(self.bn0, self.conv0p1s1(x))                     # = self.relu(self.bn0(...)), one pass when training natively
+        out = conv_bn_act(self.conv0p1s1, self.bn0, x)                # = self.relu(self.bn0(self.conv0p1s1(x))), one node when training natively
         skips = [out]
         for i in range(4):
-            out = bn_act(getattr(self, _DOWN_BN[i]), getattr(self, _DOWN[i])(out))
+            out = conv_bn_act(getattr(self, _DOWN[i]), getattr(self, _DOWN_BN[i]), out)
             out = getattr(self, "block%d" % (i + 1))(out)
             if i < 3:
                 skips.append(out)
         for i in range(4):
-            out = bn_act(getattr(self, _UP_BN[i]), getattr(self, _UP[i])(out))
+            out = conv_bn_act(getattr(self, _UP[i]), getattr(self, _UP_BN[i]), out)
             out = ME.cat(out, skips[3 - i])
             out = getattr(self, "block%d" % (i + 5))(out)
         return self.final_sematic(out)

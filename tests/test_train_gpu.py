@@ -302,3 +302,34 @@ def test_fused_batch_norm_tail_matches_the_separate_modules(dtype, tol, with_res
             assert float((a - b).abs().max()) <= t * scale, (n, c, k, float((a - b).abs().max()), scale)
         if relu:
             assert float(outs[0][0].min()) >= 0.0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-2)])
+def test_fused_training_nodes_match_the_module_path(dtype, tol):
+    """pbnet_amd/MinkowskiEngine/fused_train.py (conv -> bn -> relu and the whole residual block as ONE autograd node, the
+    residual adds inside the convolution / normalisation epilogues) against the module-by-module path on the same
+    weights: output, input gradient, every parameter gradient, running statistics."""
+    from pbnet_amd.MinkowskiEngine import fused_train
+    coords = _coords(seed=53)
+    feats = torch.randn(len(coords), 6)
+    target = torch.randn(len(coords), 32)
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(22)
+        net = Mink_unet(6, 32, arch="MinkUNet18A").to(DEV).train()
+        fused_train.ENABLED = fused
+        try:
+            xd = feats.to(DEV).to(dtype).requires_grad_(True)
+            out = net(ME.SparseTensor(xd, torch.from_numpy(coords).to(DEV))).F
+            loss = ((out.float() - target.to(DEV)) ** 2).mean()
+            loss.backward()
+        finally:
+            fused_train.ENABLED = True
+        res.append((out.detach().float(), xd.grad.float(), {k: p.grad.float() for k, p in net.named_parameters()},
+                    {k: b.clone().float() for k, b in net.named_buffers()}))
+    (o1, g1, p1, b1), (o0, g0, p0, b0) = res
+    assert _rel(o1, o0) < tol and _rel(g1, g0) < tol
+    worst = max((_rel(p1[k], p0[k]), k) for k in p0)
+    assert worst[0] < tol * (1 if dtype == torch.float32 else 3), worst
+    for k in b0:
+        assert torch.allclose(b1[k], b0[k], rtol=1e-3 if dtype != torch.float32 else 1e-5, atol=1e-3 if dtype != torch.float32 else 1e-6), k
