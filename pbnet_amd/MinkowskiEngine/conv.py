@@ -317,9 +317,10 @@ def wgrad_native(feats, grad_out, nbr, cin, cout):
         assert nbr.is_contiguous()
         k = int(nbr.shape[1])
         in_idx, out_idx, seg_begin, _ = rulebook_pairs_dev(nbr)      # no read-back: the segment ranges stay on the device
-        # the host only needs the pair count to choose the number of pair splits: a third of the table populated is the
-        # bench scene's stride-2..16 levels (12-16 of 27), stride 1 holds 7.6 of 27
-        n_pairs = max(WGRAD_PAIR_SEGMENT, (int(nbr.shape[0]) * k) // 3)
+        # the host only needs the pair count to choose the number of pair splits (too few splits = too few workgroups, too
+        # many = more partial slabs): half the table populated for cubes (the bench scene's stride-2..16 levels hold 12-16 of
+        # 27, stride 1 7.6 -- where the split count is bounded by the workgroup target anyway), a quarter for the k=2 maps
+        n_pairs = max(WGRAD_PAIR_SEGMENT, (int(nbr.shape[0]) * k) // (2 if k >= 27 else 4))
     dw = torch.empty(k, cin, cout, dtype=torch.float32, device=dev)
     ws = _WGRAD_WS.get(dev, int(lib.pbn_spconv_wgrad_workspace_bytes(k, cin, cout)))
     rc = lib.pbn_spconv_wgrad(N.c_vp(feats.data_ptr()), feats.stride(0), N.c_vp(grad_out.data_ptr()), grad_out.stride(0),

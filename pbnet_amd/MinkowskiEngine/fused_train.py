@@ -8,6 +8,8 @@ changes is the host side: a residual block is 5-7 native calls forward and 9-13 
 eight autograd nodes with their tensor wrappers -- the training step is host-bound, so this is where
 its time goes.  The residual additions ride in the epilogues: `dx = dgrad(...) + d(residual)` is the convolution's residual
 input, not a separate pass."""
+import os
+
 import torch
 
 from .. import _native as N
@@ -15,7 +17,7 @@ from .conv import spconv_forward, wgrad_native
 from .nn import _DT, _bn_workspace, _rows_ok
 
 
-ENABLED = True      # False: every caller falls back to the module-by-module path (tests, A/B)
+ENABLED = os.environ.get("PBN_TRAIN_FUSED", "1") == "1"      # False: every caller falls back to the module-by-module path
 
 
 def usable(x, *norms):

@@ -53,7 +53,7 @@ def main():
     teacher = {k: t(v).to(dev) for k, v in teacher_np.items()}
     fwd = model.forward
     model.forward = lambda *a, **k: fwd(*a, teacher=teacher, **k)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)   # train.py:331 optim.Adam; one multi-tensor launch per step
     reducer = pd.GradientReducer(model.parameters(), comm_dtype={"bf16": torch.bfloat16, "f32": torch.float32}[args.comm_dtype],
                                  overlap=not args.no_overlap)
     t_comm = [0.0]
