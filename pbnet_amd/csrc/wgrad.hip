@@ -29,12 +29,28 @@ template <> __device__ __forceinline__ float widen<__hip_bfloat16>(const __hip_b
 }
 template <> __device__ __forceinline__ float widen<__half>(const __half* p) { return __half2float(*p); }
 
+// Flat grid -> (strip, offset, pair split), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, so split s
+// is pinned to XCD s % 8 and that XCD's dispatch order walks all strips and offsets of one split before the next one --
+// the workgroups that read the SAME output-gradient rows (and neighbouring input rows) share one L2 while they run.
+struct WgradTile { int strip, k, split; bool live; };
+__device__ __forceinline__ WgradTile wgrad_tile(int strips, int K, int splits) {
+    const int i = blockIdx.x, xcd = i & 7, j = i >> 3;
+    const int inner = strips * K;
+    const int sgrp = j / inner, rem = j - sgrp * inner;
+    WgradTile t;
+    t.split = xcd + 8 * sgrp;
+    t.k = rem / strips;
+    t.strip = rem - t.k * strips;
+    t.live = t.split < splits;
+    return t;
+}
+
 struct WgradArgs {
     const void* x; const void* g;
     const long long* in_idx; const long long* out_idx;   // pair lists (nullptr: identity, pair p = row p)
     const int* seg_begin;                                 // [K+1] first segment of every offset (nullptr: one offset, n_pairs pairs)
     float* out;                                           // dW [K, cin, cout] (splits == 1) or partial [splits, K, cin, cout]
-    int ld_x, ld_g, cin, cout, K, segment, n_pairs, splits, co_groups;
+    int ld_x, ld_g, cin, cout, K, segment, n_pairs, splits, co_groups, strips;
 };
 
 template <typename T>
@@ -42,15 +58,17 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
     __shared__ float s_red[3][NTW][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kb = lane >> 4;
-    const int k = blockIdx.y;
-    const int ci0 = (blockIdx.x / a.co_groups) * 16, co0 = (blockIdx.x % a.co_groups) * (NTW * 16);
+    const WgradTile wt = wgrad_tile(a.strips, a.K, a.splits);
+    if (!wt.live) return;
+    const int k = wt.k;
+    const int ci0 = (wt.strip / a.co_groups) * 16, co0 = (wt.strip % a.co_groups) * (NTW * 16);
     // pair range of this offset, of this workgroup's split, of this wave
     long long p_lo, p_hi;
     if (a.seg_begin) { p_lo = (long long)a.seg_begin[k] * a.segment; p_hi = (long long)a.seg_begin[k + 1] * a.segment; }
     else { p_lo = 0; p_hi = a.n_pairs; }
     const long long len = p_hi - p_lo;
     const long long per_split = ((len + a.splits - 1) / a.splits + 15) & ~15LL;
-    const long long s_lo = min(p_lo + per_split * blockIdx.z, p_hi), s_hi = min(s_lo + per_split, p_hi);
+    const long long s_lo = min(p_lo + per_split * wt.split, p_hi), s_hi = min(s_lo + per_split, p_hi);
     const long long per_wave = (((s_hi - s_lo) + 3) / 4 + 3) & ~3LL;
     const long long w_lo = min(s_lo + per_wave * wave, s_hi), w_hi = min(w_lo + per_wave, s_hi);
 
@@ -121,7 +139,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
     }
     __syncthreads();
     if (wave != 0) return;
-    float* out = a.out + ((size_t)blockIdx.z * a.K + k) * (size_t)a.cin * a.cout;
+    float* out = a.out + ((size_t)wt.split * a.K + k) * (size_t)a.cin * a.cout;
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
 #pragma unroll
@@ -160,8 +178,10 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short s_g[2][W16_SP * PG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kg = lane >> 4;
-    const int k = blockIdx.y;
-    const int cib = blockIdx.x / a.co_groups, cob = blockIdx.x % a.co_groups;
+    const WgradTile wt = wgrad_tile(a.strips, a.K, a.splits);
+    if (!wt.live) return;
+    const int k = wt.k;
+    const int cib = wt.strip / a.co_groups, cob = wt.strip % a.co_groups;
     const int ci_base = cib * (CIT * 16), co_base = cob * (COT * 16);
     const int wa = wave >> 1, wb = wave & 1;
 
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
     else { p_lo = 0; p_hi = a.n_pairs; }
     const long long len = p_hi - p_lo;
     const long long per_split = ((len + a.splits - 1) / a.splits + W16_SP - 1) & ~(long long)(W16_SP - 1);
-    const long long s_lo = min(p_lo + per_split * blockIdx.z, p_hi), s_hi = min(s_lo + per_split, p_hi);
+    const long long s_lo = min(p_lo + per_split * wt.split, p_hi), s_hi = min(s_lo + per_split, p_hi);
     const int steps = (int)((s_hi - s_lo + W16_SP - 1) / W16_SP);
 
     constexpr unsigned NOREC = 0xfffffff0u, OOB = 0xfffffff8u;
@@ -268,7 +288,7 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
         }
     }
     // D layout: column = lane & 15 (co), row = kg * 4 + r (ci)
-    float* out = a.out + ((size_t)blockIdx.z * a.K + k) * (size_t)a.cin * a.cout;
+    float* out = a.out + ((size_t)wt.split * a.K + k) * (size_t)a.cin * a.cout;
 #pragma unroll
     for (int ta = 0; ta < WA; ++ta)
 #pragma unroll
@@ -361,7 +381,8 @@ extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g
     if (splits < 1) splits = 1;
     a.splits = (int)splits;
     a.out = splits > 1 ? (float*)workspace : dw;
-    const dim3 grid(strips, n_offsets, (unsigned)splits);
+    a.strips = strips;
+    const dim3 grid((unsigned)((long long)strips * n_offsets * (((int)splits + 7) & ~7)));   // wgrad_tile(): splits padded to the 8 XCDs
     if (form16) {
         if (dtype == PBN_BF16) launch16<__hip_bfloat16>(a, wa, wb, grid, stream);
         else launch16<__half>(a, wa, wb, grid, stream);
