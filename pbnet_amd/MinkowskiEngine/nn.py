@@ -235,6 +235,39 @@ def segment_pool(feats, batch_sorted, n_batch, want_max=True, want_avg=True):
     return mx, av
 
 
+class _SegmentPoolFn(torch.autograd.Function):
+    """global max pooling + global average pooling per batch index (PBNet.py:274-276 adds the two) for rows grouped by
+    ascending batch index: ONE deterministic segment-pool launch forward instead of scatter_reduce(amax) + index_add
+    (1.3 ms of atomics on a ScanNet-sized proposal set); backward = the reductions' own rules: the average spreads its
+    gradient evenly over the segment, the maximum evenly over the rows that attain it."""
+
+    @staticmethod
+    def forward(ctx, feats, batch_sorted, n_batch):
+        mx, av = segment_pool(feats.detach(), batch_sorted, n_batch)
+        b = batch_sorted.long()
+        ctx.save_for_backward(feats, b, mx)
+        ctx.n_batch = n_batch
+        return mx + av
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, b, mx = ctx.saved_tensors
+        g = g.float()
+        f = feats.float()
+        cnt = torch.bincount(b, minlength=ctx.n_batch).to(torch.float32).clamp_(min=1.0)
+        gb = g[b]
+        ties = (f == mx[b]).to(torch.float32)
+        tie_cnt = torch.zeros(ctx.n_batch, f.shape[1], dtype=torch.float32, device=f.device).index_add_(0, b, ties)
+        grad = gb / cnt[b][:, None] + gb * ties / tie_cnt[b].clamp_(min=1.0)
+        return grad.to(feats.dtype), None, None
+
+
+def global_max_plus_avg_pool(x):
+    """MinkowskiGlobalMaxPooling()(x) + MinkowskiGlobalAvgPooling()(x) with autograd, rows grouped by batch index."""
+    b, nb = _batch_index(x)
+    return _PooledTensor(_SegmentPoolFn.apply(x.F, x.C[:, 0].contiguous(), nb).to(x.F.dtype))
+
+
 class _GlobalPool(nn.Module):
     MODE = "avg"
 

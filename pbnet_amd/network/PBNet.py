@@ -352,8 +352,10 @@ class PBNet(nn.Module):
                     iou_feat = self.linear_IOU_feat(self.score_Unet(inputs_v3))
             with section("a20_pool_head"):
                 # global max + avg pooling per proposal (PBNet.py:274-276); rows are grouped by proposal id
-                if torch.is_grad_enabled():      # training: differentiable torch reductions
-                    global_feat = self.global_max_pool(iou_feat) + self.global_avg_pool(iou_feat)
+                if torch.is_grad_enabled():      # training: the same segment-pool kernel with the reductions' backward rules
+                    from ..MinkowskiEngine.nn import global_max_plus_avg_pool
+                    global_feat = global_max_plus_avg_pool(iou_feat) if iou_feat.F.is_cuda else \
+                        self.global_max_pool(iou_feat) + self.global_avg_pool(iou_feat)
                     out["clt_scores"] = self.linear_IOU(global_feat).F.view(-1)
                 else:                            # inference: one deterministic segment-pool kernel
                     from ..MinkowskiEngine.nn import segment_pool, _PooledTensor

@@ -333,3 +333,26 @@ def test_fused_training_nodes_match_the_module_path(dtype, tol):
     assert worst[0] < tol * (1 if dtype == torch.float32 else 3), worst
     for k in b0:
         assert torch.allclose(b1[k], b0[k], rtol=1e-3 if dtype != torch.float32 else 1e-5, atol=1e-3 if dtype != torch.float32 else 1e-6), k
+
+
+def test_segment_pool_with_autograd_matches_the_torch_reductions():
+    """global max + avg pooling per proposal (PBNet.py:274-276) through pbn_segment_pool with the reductions' backward rules
+    against MinkowskiGlobalMaxPooling + MinkowskiGlobalAvgPooling (scatter_reduce amax / index_add), rows grouped by id."""
+    from pbnet_amd.MinkowskiEngine.nn import global_max_plus_avg_pool
+    g = torch.Generator().manual_seed(3)
+    sizes = [1, 700, 33, 5000, 2, 64]
+    b = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    n = int(b.numel())
+    coords = torch.stack([b.int(), torch.arange(n, dtype=torch.int32), torch.zeros(n, dtype=torch.int32), torch.zeros(n, dtype=torch.int32)], 1).to(DEV)
+    f0 = torch.randn(n, 16, generator=g)
+    f0[10:20] = f0[10]                                    # ties inside a segment share the maximum's gradient
+    gy = torch.randn(len(sizes), 16, generator=g).to(DEV)
+    outs = []
+    for native in (True, False):
+        f = f0.clone().to(DEV).requires_grad_(True)
+        x = ME.SparseTensor(f, coords)
+        y = global_max_plus_avg_pool(x).F if native else (ME.MinkowskiGlobalMaxPooling()(x) + ME.MinkowskiGlobalAvgPooling()(x)).F
+        y.backward(gy)
+        outs.append((y.detach(), f.grad))
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-5
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-5
