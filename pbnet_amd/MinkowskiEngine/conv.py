@@ -338,7 +338,8 @@ def _wgrad(feats, grad_out, nbr, cin, cout):
 class _ConvFn(torch.autograd.Function):
     """Sparse convolution with autograd.  forward / dgrad run on the implicit-GEMM kernel (the input gradient of an
     output-stationary table is the same kind of table: the mirrored offset of the same map for odd kernels, the up table
-    for a k=2,s=2 convolution, the down table for its transpose); wgrad is a gather + library GEMM (see _wgrad)."""
+    for a k=2,s=2 convolution, the down table for its transpose); wgrad is the pair-list contraction of csrc/wgrad.hip
+    (wgrad_native)."""
 
     @staticmethod
     def forward(ctx, feats, kernel, bias, nbr, n_out, cache, dgrad_nbr, flip):

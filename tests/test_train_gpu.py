@@ -1,5 +1,5 @@
 """GPU tier, training path (BASELINE configs[2]): gradients of the sparse convolutions (dgrad on the implicit-GEMM
-kernel, wgrad as gather + GEMM) against torch autograd through the CPU oracle's gather-mm-index_add convolution."""
+kernel, wgrad on the matrix cores over the rule pairs) against torch autograd through the CPU oracle's gather-mm-index_add convolution."""
 import numpy as np
 import pytest
 import torch
