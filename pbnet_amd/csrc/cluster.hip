@@ -774,9 +774,9 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
     if ((member_start == nullptr) != (member_idx == nullptr)) return PBN_ERR_ARG;
     if (n > 0 && (!off_xyz || !org_xyz || !sem || !seg_len || !cluster_id || !den || !centers || !clt_sem || !workspace))
         return PBN_ERR_ARG;
-    if (n_seg > 0) PBN_HIP_CHECK(hipMemsetAsync(cluster_num, 0, sizeof(int) * (size_t)n_seg, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(n_clusters, 0, sizeof(int), stream));
     if (n == 0 || n_seg == 0) {
+        if (n_seg > 0) PBN_HIP_CHECK(hipMemsetAsync(cluster_num, 0, sizeof(int) * (size_t)n_seg, stream));
+        PBN_HIP_CHECK(hipMemsetAsync(n_clusters, 0, sizeof(int), stream));
         if (member_start) PBN_HIP_CHECK(hipMemsetAsync(member_start, 0, sizeof(int) * ((size_t)n + 1), stream));
         return PBN_OK;
     }
@@ -801,13 +801,16 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
         char* z0 = (char*)w.scalars;
         char* f0 = (char*)w.hkeys;
         char* b0 = (char*)w.cell_rep;
-        PBN_HIP_CHECK(hipMemsetAsync(z0, 0, (size_t)(base + w.zero_end - z0), stream));
-        PBN_HIP_CHECK(hipMemsetAsync(f0, 0xff, (size_t)(base + w.ff_end - f0), stream));
-        PBN_HIP_CHECK(hipMemsetAsync(b0, 0x7f, (size_t)(base + w.big_end - b0), stream));
+        // ... and the caller's counters, all in one launch (unaligned ranges fall back to hipMemsetAsync inside)
+        FillRange fr[7] = {{cluster_num, sizeof(int) * (size_t)n_seg, 0}, {n_clusters, sizeof(int), 0},
+                           {z0, (size_t)(base + w.zero_end - z0), 0}, {f0, (size_t)(base + w.ff_end - f0), 0xff},
+                           {b0, (size_t)(base + w.big_end - b0), 0x7f}, {nullptr, 0, 0}, {nullptr, 0, 0}};
         if (capacity) {   // the scans below run over the whole capacity: flags of rows that do not exist must read 0
-            PBN_HIP_CHECK(hipMemsetAsync(w.keep, 0, sizeof(int) * (size_t)n, stream));
-            PBN_HIP_CHECK(hipMemsetAsync(w.noise_flag, 0, sizeof(int) * (size_t)n, stream));
+            fr[5] = FillRange{w.keep, sizeof(int) * (size_t)n, 0};
+            fr[6] = FillRange{w.noise_flag, sizeof(int) * (size_t)n, 0};
         }
+        const int frc = fill_ranges(fr, 7, stream);
+        if (frc != PBN_OK) return frc;
     }
 
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(64), 0, stream, seg_len, n_seg, n, capacity, w.seg_off, status);

@@ -96,6 +96,45 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const int* in, int*
     }
 }
 
+struct FillArgs { uint4* p[8]; unsigned long long vecs[8]; unsigned pattern[8]; int n; };
+__global__ __launch_bounds__(256) void k_fill_ranges(const FillArgs a) {
+    unsigned long long total = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) total += r < a.n ? a.vecs[r] : 0ull;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (unsigned long long)gridDim.x * 256) {
+        unsigned long long off = e;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r >= a.n) break;
+            if (off < a.vecs[r]) { a.p[r][off] = make_uint4(a.pattern[r], a.pattern[r], a.pattern[r], a.pattern[r]); break; }
+            off -= a.vecs[r];
+        }
+    }
+}
+
+int fill_ranges(const FillRange* ranges, int n, hipStream_t stream) {
+    FillArgs a;
+    a.n = 0;
+    unsigned long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const FillRange& r = ranges[i];
+        if (!r.p || r.bytes == 0) continue;
+        if (((uintptr_t)r.p & 15) || (r.bytes & 15) || a.n == 8) { PBN_HIP_CHECK(hipMemsetAsync(r.p, r.value, r.bytes, stream)); continue; }
+        a.p[a.n] = (uint4*)r.p;
+        a.vecs[a.n] = r.bytes / 16;
+        a.pattern[a.n] = 0x01010101u * r.value;
+        total += a.vecs[a.n];
+        ++a.n;
+    }
+    if (a.n == 0) return PBN_OK;
+    long long blocks = cdiv((long long)total, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_fill_ranges, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
 int scan_exclusive_i32(const int* in, int* out, int n, int* tmp, int* total, hipStream_t stream) {
     if (n <= 0) {
         if (total) PBN_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(int), stream));

@@ -54,9 +54,12 @@ extern "C" int pbn_coords_build(const int32_t* coords, const int32_t* n_dev, int
     void* ws = A + L->workspace;
     const size_t wsb = (size_t)L->workspace_bytes;
     hipStream_t st = (hipStream_t)stream;
-    PBN_HIP_CHECK(hipMemsetAsync(A + L->counts, 0, 16 * sizeof(int), st));
-    PBN_HIP_CHECK(hipMemsetAsync(A + L->keys[0], 0xff, (size_t)(L->vals[0] - L->keys[0]), st));
-    PBN_HIP_CHECK(hipMemsetAsync(A + L->vals[0], 0x7f, (size_t)(L->unique_index - L->vals[0]), st));
+    {
+        const FillRange fr[3] = {{A + L->counts, 16 * sizeof(int), 0}, {A + L->keys[0], (size_t)(L->vals[0] - L->keys[0]), 0xff},
+                                 {A + L->vals[0], (size_t)(L->unique_index - L->vals[0]), 0x7f}};
+        const int frc = fill_ranges(fr, 3, st);
+        if (frc != PBN_OK) return frc;
+    }
     int rc = coords_unique_impl(coords, n_dev, n, (uint64_t*)(A + L->keys[0]), I(L->vals[0]), L->capacity[0],
                                 I(L->unique_index), I(L->inverse), I(L->coords[0]), counts + 0, ws, wsb, counts + 8, false,
                                 st);
@@ -129,12 +132,16 @@ static int coords_prepare_impl(const int32_t* coords, const int32_t* n_dev, int 
     auto I = [&](int64_t o) { return (int32_t*)(A + o); };
     const size_t N = (size_t)(n > 0 ? n : 1);
     // clears: the temporary table + the pyramid's three fill-pattern groups
-    PBN_HIP_CHECK(hipMemsetAsync(A + P->n_unique, 0, 16 * sizeof(int), st));
-    PBN_HIP_CHECK(hipMemsetAsync(A + P->tmp_keys, 0xff, (size_t)(P->tmp_vals - P->tmp_keys), st));
-    PBN_HIP_CHECK(hipMemsetAsync(A + P->tmp_vals, 0x7f, (size_t)(P->unique_index - P->tmp_vals), st));
-    PBN_HIP_CHECK(hipMemsetAsync(A + L->counts, 0, 16 * sizeof(int), st));
-    PBN_HIP_CHECK(hipMemsetAsync(A + L->keys[0], 0xff, (size_t)(L->vals[0] - L->keys[0]), st));
-    PBN_HIP_CHECK(hipMemsetAsync(A + L->vals[0], 0x7f, (size_t)(L->unique_index - L->vals[0]), st));
+    {   // ... in ONE launch (six hipMemsetAsync = six launches per pyramid)
+        const FillRange fr[6] = {{A + P->n_unique, 16 * sizeof(int), 0},
+                                 {A + P->tmp_keys, (size_t)(P->tmp_vals - P->tmp_keys), 0xff},
+                                 {A + P->tmp_vals, (size_t)(P->unique_index - P->tmp_vals), 0x7f},
+                                 {A + L->counts, 16 * sizeof(int), 0},
+                                 {A + L->keys[0], (size_t)(L->vals[0] - L->keys[0]), 0xff},
+                                 {A + L->vals[0], (size_t)(L->unique_index - L->vals[0]), 0x7f}};
+        const int frc = fill_ranges(fr, 6, st);
+        if (frc != PBN_OK) return frc;
+    }
     if (n == 0) return PBN_OK;
     if (!coords) return PBN_ERR_ARG;
     int32_t* n_unique = I(P->n_unique);
