@@ -775,9 +775,9 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
     if (n > 0 && (!off_xyz || !org_xyz || !sem || !seg_len || !cluster_id || !den || !centers || !clt_sem || !workspace))
         return PBN_ERR_ARG;
     if (n == 0 || n_seg == 0) {
-        if (n_seg > 0) PBN_HIP_CHECK(hipMemsetAsync(cluster_num, 0, sizeof(int) * (size_t)n_seg, stream));
-        PBN_HIP_CHECK(hipMemsetAsync(n_clusters, 0, sizeof(int), stream));
-        if (member_start) PBN_HIP_CHECK(hipMemsetAsync(member_start, 0, sizeof(int) * ((size_t)n + 1), stream));
+        if (n_seg > 0) { const int frc_ = fill_bytes(cluster_num, 0, sizeof(int) * (size_t)n_seg, stream); if (frc_ != PBN_OK) return frc_; }
+        { const int frc_ = fill_bytes(n_clusters, 0, sizeof(int), stream); if (frc_ != PBN_OK) return frc_; }
+        if (member_start) { const int frc_ = fill_bytes(member_start, 0, sizeof(int) * ((size_t)n + 1), stream); if (frc_ != PBN_OK) return frc_; }
         return PBN_OK;
     }
     Carver cv(workspace, workspace_bytes);

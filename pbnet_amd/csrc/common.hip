@@ -96,8 +96,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const int* in, int*
     }
 }
 
-struct FillArgs { uint4* p[8]; unsigned long long vecs[8]; unsigned pattern[8]; int n; };
+// Up to 8 aligned vector ranges and 16 byte ranges (unaligned heads / tails, small ranges) in one launch.  No
+// hipMemsetAsync anywhere on the capturable paths: memset NODES of a HIP graph were observed not to re-execute after an
+// explicit stream / device synchronisation between two replays on this ROCm runtime (a 240-byte table kept accumulating,
+// hash tables stayed full -> endless probe loops; scripts/debug_stop2.py), kernel nodes always do.
+struct FillArgs {
+    uint4* p[8]; unsigned long long vecs[8]; unsigned pattern[8];
+    unsigned char* bp[16]; unsigned blen[16]; unsigned char bval[16];
+    int n, nb;
+};
 __global__ __launch_bounds__(256) void k_fill_ranges(const FillArgs a) {
+    if (blockIdx.x == 0) {   // the byte ranges: a few bytes to a few hundred each
+        for (int r = 0; r < a.nb; ++r)
+            for (unsigned i = threadIdx.x; i < a.blen[r]; i += 256) a.bp[r][i] = a.bval[r];
+    }
     unsigned long long total = 0;
 #pragma unroll
     for (int r = 0; r < 8; ++r) total += r < a.n ? a.vecs[r] : 0ull;
@@ -112,32 +124,51 @@ __global__ __launch_bounds__(256) void k_fill_ranges(const FillArgs a) {
     }
 }
 
-int fill_ranges(const FillRange* ranges, int n, hipStream_t stream) {
-    FillArgs a;
-    a.n = 0;
+static void fill_flush(FillArgs& a, hipStream_t stream) {
+    if (a.n == 0 && a.nb == 0) return;
     unsigned long long total = 0;
-    for (int i = 0; i < n; ++i) {
-        const FillRange& r = ranges[i];
-        if (!r.p || r.bytes == 0) continue;
-        if (((uintptr_t)r.p & 15) || (r.bytes & 15) || a.n == 8) { PBN_HIP_CHECK(hipMemsetAsync(r.p, r.value, r.bytes, stream)); continue; }
-        a.p[a.n] = (uint4*)r.p;
-        a.vecs[a.n] = r.bytes / 16;
-        a.pattern[a.n] = 0x01010101u * r.value;
-        total += a.vecs[a.n];
-        ++a.n;
-    }
-    if (a.n == 0) return PBN_OK;
+    for (int r = 0; r < a.n; ++r) total += a.vecs[r];
     long long blocks = cdiv((long long)total, 256 * 4);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_fill_ranges, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    a.n = 0; a.nb = 0;
+}
+
+int fill_ranges(const FillRange* ranges, int n, hipStream_t stream) {
+    FillArgs a;
+    a.n = 0; a.nb = 0;
+    auto add_bytes = [&](unsigned char* p, size_t len, unsigned char v) {
+        while (len) {
+            if (a.nb == 16) fill_flush(a, stream);
+            const size_t take = len > 0xffffffffull ? 0xffffffffull : len;
+            a.bp[a.nb] = p; a.blen[a.nb] = (unsigned)take; a.bval[a.nb] = v; ++a.nb;
+            p += take; len -= take;
+        }
+    };
+    for (int i = 0; i < n; ++i) {
+        const FillRange& r = ranges[i];
+        if (!r.p || r.bytes == 0) continue;
+        unsigned char* p = (unsigned char*)r.p;
+        size_t len = r.bytes;
+        if (len < 64) { add_bytes(p, len, r.value); continue; }
+        const size_t head = (16 - ((uintptr_t)p & 15)) & 15;
+        if (head) { add_bytes(p, head, r.value); p += head; len -= head; }
+        const size_t tail = len & 15;
+        if (len >= 16) {
+            if (a.n == 8) fill_flush(a, stream);
+            a.p[a.n] = (uint4*)p; a.vecs[a.n] = len / 16; a.pattern[a.n] = 0x01010101u * r.value; ++a.n;
+        }
+        if (tail) add_bytes(p + (len - tail), tail, r.value);
+    }
+    fill_flush(a, stream);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
 
 int scan_exclusive_i32(const int* in, int* out, int n, int* tmp, int* total, hipStream_t stream) {
     if (n <= 0) {
-        if (total) PBN_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(int), stream));
+        if (total) { const int frc_ = fill_bytes(total, 0, sizeof(int), stream); if (frc_ != PBN_OK) return frc_; }
         return PBN_OK;
     }
     const int nb = cdiv(n, SCAN_TILE);

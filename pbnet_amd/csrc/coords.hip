@@ -302,9 +302,9 @@ int coords_unique_impl(const int32_t* coords, const int32_t* n_dev, int n_max, u
         !table_keys || !table_vals)
         return PBN_ERR_ARG;
     if (clear) {
-        PBN_HIP_CHECK(hipMemsetAsync(table_keys, 0xff, sizeof(uint64_t) * (size_t)capacity, stream));
-        PBN_HIP_CHECK(hipMemsetAsync(table_vals, 0x7f, sizeof(int) * (size_t)capacity, stream));
-        PBN_HIP_CHECK(hipMemsetAsync(n_unique, 0, sizeof(int), stream));
+        { const int frc_ = fill_bytes(table_keys, 0xff, sizeof(uint64_t) * (size_t)capacity, stream); if (frc_ != PBN_OK) return frc_; }
+        { const int frc_ = fill_bytes(table_vals, 0x7f, sizeof(int) * (size_t)capacity, stream); if (frc_ != PBN_OK) return frc_; }
+        { const int frc_ = fill_bytes(n_unique, 0, sizeof(int), stream); if (frc_ != PBN_OK) return frc_; }
     }
     if (n_max == 0) return PBN_OK;
     if (!coords || !unique_index || !workspace) return PBN_ERR_ARG;
@@ -312,7 +312,7 @@ int coords_unique_impl(const int32_t* coords, const int32_t* n_dev, int n_max, u
     if (!carve_ws(workspace, workspace_bytes, n_max, w)) return PBN_ERR_WORKSPACE;
     if (!status) {
         status = w.status;
-        PBN_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int) * 4, stream));
+        { const int frc_ = fill_bytes(status, 0, sizeof(int) * 4, stream); if (frc_ != PBN_OK) return frc_; }
     }
     const int nb = cdiv(n_max, TPB), nsb = cdiv(n_max, SCAN_TILE);
     const unsigned mask = (unsigned)capacity - 1;
@@ -336,15 +336,15 @@ int coords_stride_impl(const int32_t* fine_coords, const int32_t* n_fine_dev, in
         (long long)capacity < 2LL * n_fine_max || !n_coarse || !table_keys || !table_vals)
         return PBN_ERR_ARG;
     if (clear) {
-        PBN_HIP_CHECK(hipMemsetAsync(table_keys, 0xff, sizeof(uint64_t) * (size_t)capacity, stream));
-        PBN_HIP_CHECK(hipMemsetAsync(table_vals, 0x7f, sizeof(int) * (size_t)capacity, stream));
-        PBN_HIP_CHECK(hipMemsetAsync(n_coarse, 0, sizeof(int), stream));
+        { const int frc_ = fill_bytes(table_keys, 0xff, sizeof(uint64_t) * (size_t)capacity, stream); if (frc_ != PBN_OK) return frc_; }
+        { const int frc_ = fill_bytes(table_vals, 0x7f, sizeof(int) * (size_t)capacity, stream); if (frc_ != PBN_OK) return frc_; }
+        { const int frc_ = fill_bytes(n_coarse, 0, sizeof(int), stream); if (frc_ != PBN_OK) return frc_; }
     }
     if (n_fine_max == 0) return PBN_OK;
     if (!fine_coords || !coarse_coords || !parent_row || !child_k || !nbr_down || !workspace) return PBN_ERR_ARG;
     CoordWs w;
     if (!carve_ws(workspace, workspace_bytes, n_fine_max, w)) return PBN_ERR_WORKSPACE;
-    if (clear) PBN_HIP_CHECK(hipMemsetAsync(nbr_down, 0xff, sizeof(int) * 8 * (size_t)n_fine_max, stream));
+    if (clear) { const int frc_ = fill_bytes(nbr_down, 0xff, sizeof(int) * 8 * (size_t)n_fine_max, stream); if (frc_ != PBN_OK) return frc_; }
     const int nb = cdiv(n_fine_max, TPB), nsb = cdiv(n_fine_max, SCAN_TILE);
     const unsigned mask = (unsigned)capacity - 1;
     hipLaunchKernelGGL(k_insert_parents, dim3(nb), dim3(TPB), 0, stream, fine_coords, n_fine_dev, n_fine_max, stride_out,

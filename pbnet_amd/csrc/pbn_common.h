@@ -69,10 +69,14 @@ static inline size_t scan_tmp_ints(long long n) { return (size_t)cdiv(n, SCAN_TI
 // out[i] = sum_{j<i} in[j] for i in [0,n); if total != nullptr, *total = sum of all.  in may alias out.
 int scan_exclusive_i32(const int* in, int* out, int n, int* tmp, int* total, hipStream_t stream);
 
-// Several byte fills in ONE launch (a stage's zero / 0xff / 0x7f groups: each hipMemsetAsync is a launch of its own).  Up to
-// 8 ranges; a range that is not 16-byte aligned at both ends goes through hipMemsetAsync.
+// Several byte fills in ONE kernel launch (a stage's zero / 0xff / 0x7f groups), any alignment and size; replaces
+// hipMemsetAsync on every path that may be captured in a HIP graph (see common.hip for why).
 struct FillRange { void* p; size_t bytes; unsigned char value; };
 int fill_ranges(const FillRange* ranges, int n, hipStream_t stream);
+static inline int fill_bytes(void* p, unsigned char value, size_t bytes, hipStream_t stream) {
+    const FillRange r{p, bytes, value};
+    return fill_ranges(&r, 1, stream);
+}
 
 // coords.hip internals shared with executor.hip (see the definitions for the `clear` contract)
 int coords_unique_impl(const int32_t* coords, const int32_t* n_dev, int n_max, uint64_t* table_keys, int32_t* table_vals,

@@ -299,7 +299,7 @@ extern "C" int pbn_local_plan(const int32_t* cluster_num, int n_segments, int nb
     int* scene_base = cv.take<int>(c_cap);
     int* scene_ent = cv.take<int>((size_t)c_cap * (MAX_K + 1));
     float* scene_w = cv.take<float>((size_t)c_cap * (MAX_K + 1));
-    PBN_HIP_CHECK(hipMemsetAsync(scene_n_ent, 0, sizeof(int) * (size_t)c_cap, stream));
+    { const int frc_ = fill_bytes(scene_n_ent, 0, sizeof(int) * (size_t)c_cap, stream); if (frc_ != PBN_OK) return frc_; }
     hipLaunchKernelGGL(k_plan_scenes, dim3(c_cap), dim3(64), 0, stream, cluster_num, n_segments, nb, member_start, centers,
                        thr02, kmax, n_clusters, c_cap, scene_n_ent, scene_ent, scene_w, counts);
     hipLaunchKernelGGL(k_plan_pack, dim3(1), dim3(PACK_TPB), 0, stream, scene_n_ent, scene_ent, scene_w, member_start,

@@ -169,7 +169,7 @@ extern "C" int pbn_proposal_bitmask(const int64_t* proposals_idx, int n_entries,
     if (n_prop == 0) return PBN_OK;
     if (!masks || !counts || (n_entries > 0 && !proposals_idx)) return PBN_ERR_ARG;
     const int words = pbn_post_words(n_fold);
-    PBN_HIP_CHECK(hipMemsetAsync(masks, 0, sizeof(uint32_t) * (size_t)n_prop * words, stream));
+    { const int frc_ = fill_bytes(masks, 0, sizeof(uint32_t) * (size_t)n_prop * words, stream); if (frc_ != PBN_OK) return frc_; }
     if (n_entries > 0)
         hipLaunchKernelGGL(k_set_bits, dim3(cdiv(n_entries, TPB)), dim3(TPB), 0, stream, (const long long*)proposals_idx,
                            n_entries, n_fold, n_prop, words, masks);
@@ -199,8 +199,8 @@ extern "C" int pbn_superpoint_refine(const uint32_t* masks, const int32_t* pick,
         return PBN_ERR_ARG;
     const int words = pbn_post_words(n_fold);
     const int nb = cdiv(n_fold, TPB);
-    PBN_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * (size_t)n_sp * (n_pick + 1), stream));
-    if (n_pick > 0) PBN_HIP_CHECK(hipMemsetAsync(masks_out, 0, sizeof(uint32_t) * (size_t)n_pick * words, stream));
+    { const int frc_ = fill_bytes(hist, 0, sizeof(int) * (size_t)n_sp * (n_pick + 1), stream); if (frc_ != PBN_OK) return frc_; }
+    if (n_pick > 0) { const int frc_ = fill_bytes(masks_out, 0, sizeof(uint32_t) * (size_t)n_pick * words, stream); if (frc_ != PBN_OK) return frc_; }
     hipLaunchKernelGGL(k_point_labels, dim3(nb), dim3(TPB), 0, stream, masks, pick, n_pick, words, n_fold, (long long*)seg);
     hipLaunchKernelGGL(k_sp_hist, dim3(nb), dim3(TPB), 0, stream, (const long long*)seg, (const long long*)superpoint, n_fold,
                        n_sp, n_pick, hist);
@@ -230,7 +230,7 @@ extern "C" int pbn_instance_overlap(const int32_t* masks, int n_pred, int n_pts,
     if (n_pred < 0 || n_pts < 0 || n_gt < 1) return PBN_ERR_ARG;
     if (n_pred == 0) return PBN_OK;
     if (!inter) return PBN_ERR_ARG;
-    PBN_HIP_CHECK(hipMemsetAsync(inter, 0, sizeof(int32_t) * (size_t)n_pred * n_gt, stream));
+    { const int frc_ = fill_bytes(inter, 0, sizeof(int32_t) * (size_t)n_pred * n_gt, stream); if (frc_ != PBN_OK) return frc_; }
     if (n_pts == 0) return PBN_OK;
     if (!masks || !gt_index) return PBN_ERR_ARG;
     hipLaunchKernelGGL(k_instance_overlap, dim3(cdiv(n_pts, OVERLAP_CHUNK), n_pred), dim3(TPB), 0, stream, masks, n_pts,

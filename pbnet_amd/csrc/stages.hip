@@ -588,7 +588,7 @@ extern "C" int pbn_sem_argmax_table(const void* score, int ld, int n_cls, const 
                                     pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0 || n_cls < 1 || n_cls > SEL_MAX_CLASSES || nb < 1 || nb > 8 || ld < n_cls || !table) return PBN_ERR_ARG;
-    PBN_HIP_CHECK(hipMemsetAsync(table, 0, sizeof(int) * (size_t)n_cls * nb, stream));
+    { const int frc_ = fill_bytes(table, 0, sizeof(int) * (size_t)n_cls * nb, stream); if (frc_ != PBN_OK) return frc_; }
     if (n == 0) return PBN_OK;
     if (!score || !sem_pred || !block_hist) return PBN_ERR_ARG;
     const dim3 grid(cdiv(n, SEL_BLOCK));
@@ -642,7 +642,7 @@ static int mask_count_impl(const void* mask_score, int ld, float thd, const int6
     if (n < 0 || n_scenes < 0 || ld < 1) return PBN_ERR_ARG;
     if (n_scenes > 0) {
         if (!per_scene) return PBN_ERR_ARG;
-        PBN_HIP_CHECK(hipMemsetAsync(per_scene, 0, sizeof(int) * (size_t)n_scenes, stream));
+        { const int frc_ = fill_bytes(per_scene, 0, sizeof(int) * (size_t)n_scenes, stream); if (frc_ != PBN_OK) return frc_; }
     }
     if (n == 0) return PBN_OK;
     if (!mask_score || !row_scene || !block_cnt) return PBN_ERR_ARG;
@@ -833,7 +833,7 @@ extern "C" int pbn_rulebook_pair_counts(const int32_t* nbr, int n, int n_offsets
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0 || n_offsets < 1) return PBN_ERR_ARG;
     if (!totals) return PBN_ERR_ARG;
-    if (n == 0) { PBN_HIP_CHECK(hipMemsetAsync(totals, 0, sizeof(int32_t) * n_offsets, stream)); return PBN_OK; }
+    if (n == 0) { { const int frc_ = fill_bytes(totals, 0, sizeof(int32_t) * n_offsets, stream); if (frc_ != PBN_OK) return frc_; } return PBN_OK; }
     if (!nbr || !table) return PBN_ERR_ARG;
     const int nb = pbn_rulebook_pair_blocks(n);
     hipLaunchKernelGGL(k_pair_count, dim3(nb), dim3(TPB), 0, stream, nbr, n, n_offsets, table);
@@ -850,9 +850,9 @@ extern "C" int pbn_rulebook_pair_fill(const int32_t* nbr, int n, int n_offsets, 
     if (n_segments == 0) return PBN_OK;
     if (!in_idx || !out_idx || !seg_offset) return PBN_ERR_ARG;
     // padding slots (and surplus segments) read as -1 / offset 0
-    PBN_HIP_CHECK(hipMemsetAsync(in_idx, 0xff, sizeof(int64_t) * (size_t)n_segments * seg, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(out_idx, 0xff, sizeof(int64_t) * (size_t)n_segments * seg, stream));
-    PBN_HIP_CHECK(hipMemsetAsync(seg_offset, 0, sizeof(int64_t) * (size_t)n_segments, stream));
+    { const int frc_ = fill_bytes(in_idx, 0xff, sizeof(int64_t) * (size_t)n_segments * seg, stream); if (frc_ != PBN_OK) return frc_; }
+    { const int frc_ = fill_bytes(out_idx, 0xff, sizeof(int64_t) * (size_t)n_segments * seg, stream); if (frc_ != PBN_OK) return frc_; }
+    { const int frc_ = fill_bytes(seg_offset, 0, sizeof(int64_t) * (size_t)n_segments, stream); if (frc_ != PBN_OK) return frc_; }
     if (n == 0) return PBN_OK;
     if (!nbr || !table || !seg_start) return PBN_ERR_ARG;
     hipLaunchKernelGGL(k_pair_fill, dim3(pbn_rulebook_pair_blocks(n)), dim3(TPB), 0, stream, nbr, n, n_offsets, table, seg_start,

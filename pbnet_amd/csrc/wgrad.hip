@@ -349,7 +349,7 @@ extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g
     if (!seg_begin && n_offsets != 1) return PBN_ERR_ARG;
     const long long n_out = (long long)n_offsets * cin * cout;
     if (n_pairs_total == 0) {
-        PBN_HIP_CHECK(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)n_out, stream));
+        { const int frc_ = fill_bytes(dw, 0, sizeof(float) * (size_t)n_out, stream); if (frc_ != PBN_OK) return frc_; }
         return PBN_OK;
     }
     if (!x || !g) return PBN_ERR_ARG;

@@ -196,12 +196,12 @@ class PlannedForward(object):
         coords1 = xyz_voxel.to(torch.int32).contiguous()
         lin1 = _Lineage(coords1, n_vox, None, dev)
         if _STOP == "prepare1":
-            return {"counts": counts, "_keep": (lin1, coords1)}
+            return {"counts": counts, "_keep": {"lin1": lin1, "coords1": coords1}}
         feats1 = feat_voxel.contiguous()
         f = self._unet(m.MEUnet, lin1, cap.lv1, feats1, feats1.shape[1] * es)
         _dbg("backbone done", counts)
         if _STOP == "backbone":
-            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
+            return {"counts": counts, "_keep": {k: v for k, v in locals().items() if torch.is_tensor(v) or isinstance(v, _Lineage)}}
         v2p = v2p_index.long()
         v2p_z = lin1.inv_perm[v2p]                                   # Z-order row of every point's voxel
         point_feat_p = f[v2p_z]
@@ -216,7 +216,7 @@ class PlannedForward(object):
 
         _dbg("heads done", counts)
         if _STOP == "heads":
-            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
+            return {"counts": counts, "_keep": {k: v for k, v in locals().items() if torch.is_tensor(v) or isinstance(v, _Lineage)}}
         # ---- class gate -> selection -> grouping (PBNet.py:151-179), sizes on the device ----
         n_cls = int(m.sem_num)
         n_seg = (n_cls - 2) * nb
@@ -230,7 +230,7 @@ class PlannedForward(object):
 
         _dbg("grouping done", counts)
         if _STOP == "grouping":
-            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
+            return {"counts": counts, "_keep": {k: v for k, v in locals().items() if torch.is_tensor(v) or isinstance(v, _Lineage)}}
         # ---- local scenes (PBNet.py:182-234): plan on the device, rows by one launch ----
         c_cap, e_cap, r_cap = int(cap.clusters), int(cap.entries), int(cap.rows)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -260,7 +260,7 @@ class PlannedForward(object):
 
         _dbg("local scene rows done", counts)
         if _STOP == "local scene rows":
-            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
+            return {"counts": counts, "_keep": {k: v for k, v in locals().items() if torch.is_tensor(v) or isinstance(v, _Lineage)}}
         # ---- mask branch (PBNet.py:236-252) ----
         lin2 = _Lineage(coords2, r_cap, cnt(CNT.ROWS), dev)
         f2 = self._unet(m.D_Unet, lin2, cap.lv2, feat2, ld2 * es)
@@ -268,7 +268,7 @@ class PlannedForward(object):
 
         _dbg("mask branch done", counts)
         if _STOP == "mask branch":
-            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
+            return {"counts": counts, "_keep": {k: v for k, v in locals().items() if torch.is_tensor(v) or isinstance(v, _Lineage)}}
         # ---- proposals (PBNet.py:317-347) ----
         per_scene = torch.empty(c_cap, **i32)
         block_cnt = torch.empty(max(int(lib.pbn_select_blocks(r_cap)), 1), **i32)
@@ -291,7 +291,7 @@ class PlannedForward(object):
 
         _dbg("proposals done", counts)
         if _STOP == "proposals":
-            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
+            return {"counts": counts, "_keep": {k: v for k, v in locals().items() if torch.is_tensor(v) or isinstance(v, _Lineage)}}
         # ---- score branch (PBNet.py:255-279) ----
         lin3 = _Lineage(coords3, r_cap, cnt(CNT.PROPOSAL_ROWS), dev)
         f3 = self._unet(m.score_Unet, lin3, cap.lv3, feat3, c_in * es)
@@ -311,7 +311,7 @@ class PlannedForward(object):
         clt_scores = stage_ops.mlp_rows(m.linear_IOU, pooled).view(-1)
         _dbg("score branch done", counts)
         if _STOP == "score branch":
-            return {"counts": counts, "_keep": tuple(v for v in locals().values() if torch.is_tensor(v) or isinstance(v, _Lineage))}
+            return {"counts": counts, "_keep": {k: v for k, v in locals().items() if torch.is_tensor(v) or isinstance(v, _Lineage)}}
         # a level of one of the three pyramids that outgrew its capacity (rows were dropped): flag it
         ovf = torch.stack(self._level_overflow).any().to(torch.int32) * 64
         counts[CNT.OVERFLOW:CNT.OVERFLOW + 1] |= ovf
@@ -364,10 +364,10 @@ class PlannedForward(object):
     def replay(self, feat_voxel=None, xyz_voxel=None, xyz_original=None, v2p_index=None, teacher=None):
         """Copy new inputs (same shapes) into the static buffers and launch the graph on a stream of its own, joined with
         the caller's current stream by events on both sides.
-        KNOWN ISSUE (ROCm 7.0 runtime of this image, open): at ScanNet scene size, eager torch kernels issued BETWEEN two
-        replays (e.g. torch.equal on the outputs) can make the next launch of the graph never complete -- reproduced with a
-        graph that holds nothing but the coordinate pipeline (scripts/debug_stop2.py, scripts/debug_variants.py variant E);
-        back-to-back replay + finish loops (scripts/debug_inflight_graph.py, 4-8 host threads) and small scenes are fine."""
+        Replays may be interleaved with anything (eager kernels on the outputs, read-backs, synchronisations): every fill
+        the launch sequence needs is a kernel node (csrc/common.hip fill_ranges) -- hipMemsetAsync nodes turned out not to
+        re-execute after an explicit stream / device synchronisation between two replays on this ROCm runtime, which used to
+        leave hash tables full (endless probe loops) and count tables accumulating."""
         cur = torch.cuda.current_stream(self.dev)
         if self._replay_stream is None:
             self._replay_stream = torch.cuda.Stream(self.dev)

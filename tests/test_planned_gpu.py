@@ -167,12 +167,20 @@ def test_bench_scene_planned_bf16():
     _same_proposals(got, want, 2e-2)
 
     pf.capture(*_args(b), teacher=t)
-    reps = [pf.finish(pf.replay()) for _ in range(3)]          # back to back, as a serving loop replays
-    torch.cuda.synchronize()
-    # compared only after the LAST replay: eager kernels between replays of a scene-sized graph can hang this ROCm runtime
-    # (open issue, see PlannedForward.replay); the small-scene graph test above does interleave them
-    rep = reps[-1]
-    for a_, w_ in zip(rep["proposals"], got["proposals"]):
-        assert torch.equal(a_, w_)
-    assert torch.equal(rep["clt_scores"], got["clt_scores"])
+    # replays interleaved with everything a caller may do between them: eager kernels on the graph's outputs, read-backs,
+    # stream and device synchronisations.  (Until the library's fills became kernels this hung or returned garbage from
+    # the second replay on: hipMemsetAsync nodes of a captured graph do not re-execute reliably after an explicit
+    # synchronisation on this ROCm runtime -- csrc/common.hip, fill_ranges.)
+    for it in range(4):
+        rep = pf.finish(pf.replay())
+        for a_, w_ in zip(rep["proposals"], got["proposals"]):
+            assert torch.equal(a_, w_), it
+        assert torch.equal(rep["clt_scores"], got["clt_scores"]), it
+        if it == 0:
+            torch.cuda.synchronize()
+        elif it == 1:
+            torch.cuda.current_stream().synchronize()
+            _ = float(rep["clt_scores"].float().sum().item())
+        elif it == 2:
+            _ = torch.ones(1 << 20, device=DEV).sum().item()
     # timings of the three forms live in scripts/debug_planned.py / scripts/debug_inflight_graph.py
