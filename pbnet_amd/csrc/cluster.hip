@@ -221,27 +221,79 @@ __global__ __launch_bounds__(TPB) void k_count(const float4* __restrict__ spt, c
                                               float inv_cell, float r2, const unsigned long long* __restrict__ hkeys,
                                               unsigned hmask, const int* __restrict__ hstart,
                                               const int* __restrict__ hcount, int* __restrict__ den) {
+    // The 8 points of a wave are neighbours in the cell-sorted slab: in 82 % of the waves (90 % of the tests) they share a
+    // cell, hence the 125 candidate ranges.  Then the wave loads every candidate ONCE -- 64 per load, one per lane,
+    // through a per-wave LDS line, the next 64 already in flight -- and each point's 8 lanes test them from there instead
+    // of 8 groups fetching the same candidates from L2; waves whose groups look at different cells keep the per-group
+    // walk.  Integer counts: order-free.  Bench scene (64 k points, 3e8 tests): 298 -> 274 us, of which the hash probes are
+    // 30.  Also measured, none of them better: packed fp32 tests (298), a per-cell table of the 125 neighbour slots (269, + 16
+    // to build and 500 B of workspace per point), cell-by-cell passes so that every test takes the shared path (378), a
+    // cell-tiled kernel with candidates through the scalar cache (477).
+    __shared__ float4 s_cand[TPB / 64][64];
     const int n = n_ref.get();
+    if (n <= 0) return;
     const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
     int p = (int)(t / NB_Q);
     const int q = (int)(t % NB_Q);
     const bool live = p < n;
     if (!live) p = n - 1;  // keep the lane group complete for the shuffles
     const float4 me = spt[p];
+    const int seg = sseg[p];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gbase = lane & ~(NB_Q - 1);
+    float4* line = s_cand[wave];
     int cnt = 0;
-    for_each_neighbour_cell_group(me.x, me.y, me.z, sseg[p], inv_cell, hkeys, hmask, hstart, hcount, q,
-                                  [&](int beg, int end, int, bool, bool) {
-        int j = beg + q;
-        for (; j + NB_Q < end; j += 2 * NB_Q) {  // two independent loads in flight
-            const float4 q0 = spt[j], q1 = spt[j + NB_Q];
-            cnt += (sqdist(me.x, me.y, me.z, q0.x, q0.y, q0.z) <= r2) ? 1 : 0;
-            cnt += (sqdist(me.x, me.y, me.z, q1.x, q1.y, q1.z) <= r2) ? 1 : 0;
+    const int cx = cell_coord(me.x, inv_cell), cy = cell_coord(me.y, inv_cell), cz = cell_coord(me.z, inv_cell);
+    constexpr int W = 2 * CELL_R + 1;
+    for (int r = 0; r < W * W * W; r += NB_Q) {
+        const int c = r + q;
+        int slot = -1, beg = 0, end = 0;
+        if (c < W * W * W) {
+            const int dz = c / (W * W) - CELL_R, dy = (c / W) % W - CELL_R, dx = c % W - CELL_R;
+            slot = hash_lookup(hkeys, hmask, pack_key(seg, cx + dx, cy + dy, cz + dz));
+            if (slot >= 0) { beg = hstart[slot]; end = beg + hcount[slot]; }
         }
-        for (; j < end; j += NB_Q) {
-            const float4 q0 = spt[j];
-            cnt += (sqdist(me.x, me.y, me.z, q0.x, q0.y, q0.z) <= r2) ? 1 : 0;
+        // do all 8 groups of the wave look at the same 8 ranges?
+        const bool same = beg == __shfl(beg, q, 64) && end == __shfl(end, q, 64);
+        if (__all(same)) {
+#pragma unroll 1
+            for (int k = 0; k < NB_Q; ++k) {
+                const int bk = __shfl(beg, k, 64), ek = __shfl(end, k, 64);   // wave-uniform
+                float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bk + lane < ek) nxt = spt[bk + lane];
+                for (int cb = bk; cb < ek; cb += 64) {
+                    line[lane] = nxt;
+                    if (cb + 64 + lane < ek) nxt = spt[cb + 64 + lane];      // lands behind this chunk's tests
+                    const int m = min(64, ek - cb);
+#pragma unroll
+                    for (int i = 0; i < 64 / NB_Q; ++i) {
+                        const int idx = q + NB_Q * i;
+                        if (idx < m) {
+                            const float4 v = line[idx];
+                            cnt += (sqdist(me.x, me.y, me.z, v.x, v.y, v.z) <= r2) ? 1 : 0;
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB_Q; ++k) {
+                const int sk = __shfl(slot, gbase + k, 64);
+                if (sk < 0) continue;
+                const int bk = __shfl(beg, gbase + k, 64), ek = __shfl(end, gbase + k, 64);
+                int j = bk + q;
+                for (; j + NB_Q < ek; j += 2 * NB_Q) {  // two independent loads in flight
+                    const float4 q0 = spt[j], q1 = spt[j + NB_Q];
+                    cnt += (sqdist(me.x, me.y, me.z, q0.x, q0.y, q0.z) <= r2) ? 1 : 0;
+                    cnt += (sqdist(me.x, me.y, me.z, q1.x, q1.y, q1.z) <= r2) ? 1 : 0;
+                }
+                for (; j < ek; j += NB_Q) {
+                    const float4 q0 = spt[j];
+                    cnt += (sqdist(me.x, me.y, me.z, q0.x, q0.y, q0.z) <= r2) ? 1 : 0;
+                }
+            }
         }
-    });
+    }
     cnt = group_sum(cnt);
     if (live && q == 0) den[__float_as_int(me.w)] = cnt - 1;  // binary_cuda_functions.cu:88
 }
