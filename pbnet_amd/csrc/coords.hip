@@ -429,6 +429,47 @@ __global__ __launch_bounds__(TPB) void k_kernel_map_cube(const int* __restrict__
     }
 }
 }  // namespace
+
+// All cube maps of a pyramid (the k=3 map of every level, the k=5 map of level 0) in ONE launch: job j covers
+// n_j * K_j table entries, the grid strides over their concatenation (row counts are read on the device).
+namespace {
+__global__ __launch_bounds__(TPB) void k_kernel_maps_multi(const MapJobs jb) {
+    long long first[7];
+    first[0] = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        long long cnt = 0;
+        if (j < jb.n_jobs) cnt = (long long)real_n(jb.n_dev[j], jb.n_max) * (jb.ksize[j] * jb.ksize[j] * jb.ksize[j]);
+        first[j + 1] = first[j] + cnt;
+    }
+    for (long long g = (long long)blockIdx.x * TPB + threadIdx.x; g < first[6]; g += (long long)gridDim.x * TPB) {
+        int j = 0;
+#pragma unroll
+        for (int t = 1; t < 6; ++t) j += (t < jb.n_jobs && g >= first[t]) ? 1 : 0;
+        const long long e = g - first[j];
+        const int ksize = jb.ksize[j], K = ksize * ksize * ksize, stride = jb.stride[j];
+        const int c0 = (ksize & 1) ? ksize / 2 : 0;
+        const int row = (int)(e / K), k = (int)(e % K);
+        const int a = k % ksize - c0, b = (k / ksize) % ksize - c0, c = k / (ksize * ksize) - c0;
+        const int dx = (jb.x_fastest ? a : c) * stride, dy = b * stride, dz = (jb.x_fastest ? c : a) * stride;
+        const int4 cc = reinterpret_cast<const int4*>(jb.coords[j])[row];
+        const int x = cc.y + dx, y = cc.z + dy, z = cc.w + dz;
+        int r = -1;
+        if (in_range(cc.x, x, y, z)) r = table_find(jb.keys[j], jb.vals[j], jb.mask[j], pack4(cc.x, x, y, z));
+        jb.nbr[j][e] = r;
+    }
+}
+}  // namespace
+
+int kernel_maps_multi(const MapJobs& jb, long long total_max, hipStream_t stream) {
+    if (jb.n_jobs < 1 || jb.n_jobs > 6) return PBN_ERR_ARG;
+    if (total_max <= 0) return PBN_OK;
+    long long blocks = cdiv(total_max, TPB);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_kernel_maps_multi, dim3((unsigned)blocks), dim3(TPB), 0, stream, jb);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
 }  // namespace pbn
 
 extern "C" int pbn_kernel_map_cube(const int32_t* out_coords, const int32_t* n_out_dev, int n_out_max, int kernel_size,

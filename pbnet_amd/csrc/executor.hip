@@ -82,14 +82,20 @@ int pbn::coords_build_upper(int n, int want_k5, int x_fastest, void* arena, cons
                                 I(L->nbr_down[l]), I(L->up[l]), counts + l + 1, ws, wsb, false, st);
         if (rc != PBN_OK) return rc;
     }
-    for (int l = 0; l < 5; ++l) {
-        rc = pbn_kernel_map_cube(I(L->coords[l]), counts + l, n, 3, 1 << l, x_fastest, (const uint64_t*)(A + L->keys[l]),
-                                 I(L->vals[l]), L->capacity[l], I(L->k3[l]), st);
-        if (rc != PBN_OK) return rc;
-    }
-    if (want_k5) {
-        rc = pbn_kernel_map_cube(I(L->coords[0]), counts + 0, n, 5, 1, x_fastest, (const uint64_t*)(A + L->keys[0]),
-                                 I(L->vals[0]), L->capacity[0], I(L->k5), st);
+    {   // the k=3 map of every level and the k=5 map of level 0: one launch
+        MapJobs jb;
+        jb.n_jobs = 0; jb.n_max = n; jb.x_fastest = x_fastest;
+        long long total = 0;
+        auto add = [&](int l, int ksize, int32_t* out) {
+            const int j = jb.n_jobs++;
+            jb.coords[j] = I(L->coords[l]); jb.n_dev[j] = counts + l; jb.keys[j] = (const unsigned long long*)(A + L->keys[l]);
+            jb.vals[j] = I(L->vals[l]); jb.nbr[j] = out; jb.mask[j] = (unsigned)L->capacity[l] - 1; jb.ksize[j] = ksize;
+            jb.stride[j] = 1 << l;
+            total += (long long)n * ksize * ksize * ksize;
+        };
+        for (int l = 0; l < 5; ++l) add(l, 3, I(L->k3[l]));
+        if (want_k5) add(0, 5, I(L->k5));
+        rc = kernel_maps_multi(jb, total, st);
         if (rc != PBN_OK) return rc;
     }
     return PBN_OK;

@@ -69,6 +69,14 @@ static inline size_t scan_tmp_ints(long long n) { return (size_t)cdiv(n, SCAN_TI
 // out[i] = sum_{j<i} in[j] for i in [0,n); if total != nullptr, *total = sum of all.  in may alias out.
 int scan_exclusive_i32(const int* in, int* out, int n, int* tmp, int* total, hipStream_t stream);
 
+// coords.hip: every cube map of a pyramid in one launch (see the definition)
+struct MapJobs {
+    const int* coords[6]; const int* n_dev[6]; const unsigned long long* keys[6]; const int* vals[6]; int* nbr[6];
+    unsigned mask[6]; int ksize[6], stride[6];
+    int n_jobs, n_max, x_fastest;
+};
+int kernel_maps_multi(const MapJobs& jobs, long long total_max, hipStream_t stream);
+
 // Several byte fills in ONE kernel launch (a stage's zero / 0xff / 0x7f groups), any alignment and size; replaces
 // hipMemsetAsync on every path that may be captured in a HIP graph (see common.hip for why).
 struct FillRange { void* p; size_t bytes; unsigned char value; };
