@@ -25,7 +25,7 @@ for i in range(M):
     with torch.cuda.stream(streams[i]):
         pf = planned.PlannedForward(model, cap, dtype=torch.bfloat16)
         pf(*args, teacher=t)
-        if MODE == "graph":
+        if MODE in ("graph", "graph_nosync"):
             pf.capture(*args, teacher=t)
         pfs.append(pf)
     torch.cuda.synchronize()
@@ -35,7 +35,9 @@ def worker(i, n):
     torch.cuda.set_device(DEV)
     with torch.cuda.stream(streams[i]):
         for _ in range(i, n, M):
-            if MODE == "graph":
+            if MODE == "graph_nosync":          # no read-back at all between replays: the device-side ceiling
+                pfs[i].replay()
+            elif MODE == "graph":
                 pfs[i].finish(pfs[i].replay())
             else:
                 pfs[i](*args, teacher=t)
