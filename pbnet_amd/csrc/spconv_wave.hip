@@ -27,6 +27,18 @@ constexpr unsigned OOB = 0x80000000u;   // >= num_records of either resource: th
 constexpr unsigned UNIT_NONE = 0xffff0000u;   // step 0 (any valid weight address), offset 255 (no such offset): adds zeros
 
 constexpr int MAX_DEPTH = 8;
+
+// Cycle stamps (debug build only: make timing -> libpbnet_hip_timing.so, scripts/wave_timing.py): lane 0 of every wave of
+// the first WT_BLOCKS workgroups records s_memtime at 8 points, stamp 7 = s_memrealtime (100 MHz, comparable across CUs).
+#ifdef PBN_CONV_TIMING
+constexpr int WT_BLOCKS = 1024;
+__device__ unsigned long long g_wave_timing[WT_BLOCKS * 8 * 8 + 8];
+#define PBN_WSTAMP(I)                                                                                                 \
+    if (lane == 0 && wt_blk < WT_BLOCKS && wave < 8)                                                                  \
+        g_wave_timing[(wt_blk * 8 + wave) * 8 + (I)] = (I) == 7 ? wall_clock64() : __builtin_readcyclecounter();
+#else
+#define PBN_WSTAMP(I)
+#endif
 // units in flight per wave.  Measured on the bench scene (scripts/probe_wave.py): 2 beats the deeper pipelines on every
 // level -- occupancy (registers) and the issue cost of the extra in-flight loads outweigh the latency they would hide
 constexpr int pipe_depth(int nf, int nt) {
@@ -84,6 +96,12 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PBN_CONV_TIMING
+    const int wt_blk = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tid == 0 && wt_blk == 0) { g_wave_timing[WT_BLOCKS * 64] = gridDim.x; g_wave_timing[WT_BLOCKS * 64 + 1] = gridDim.y; }
+#endif
+    PBN_WSTAMP(7);
+    PBN_WSTAMP(0);
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
     const int row0 = xcd_tile(blockIdx.x, gridDim.x) * TM;
     if (row0 >= n) return;
@@ -109,6 +127,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
         }
     }
     __syncthreads();
+    PBN_WSTAMP(1);
 
     // ---- which offsets are populated among this wave's rows (K <= 128: two ballots) ----
     const int wrow0 = KSPLIT ? 0 : wave * RW;
@@ -169,6 +188,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     // the list is wave-private and a wave's LDS operations execute in order: the reads below follow the writes above
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    PBN_WSTAMP(2);
 
     f32x4 acc[NF][NT];
 #pragma unroll
@@ -224,6 +244,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
         Stage<NF, NT> st[B];
 #pragma unroll
         for (int s = 0; s < B; ++s) issue(st[s], s);
+        PBN_WSTAMP(3);
         for (int i = 0; i < n_units; i += B) {
 #pragma unroll
             for (int s = 0; s < B; ++s) {
@@ -233,6 +254,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
         }
         // the trailing issues read sentinels: harmless loads that are never consumed
     }
+    PBN_WSTAMP(4);
 
     if constexpr (!KSPLIT) {
 #pragma unroll
@@ -257,6 +279,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
                         make_float4(v[0], v[1], v[2], v[3]);
                 }
             __syncthreads();
+            if (t0 == 0) { PBN_WSTAMP(5); }
             for (int e = tid; e < TM * (RP / 4); e += TPB) {
                 const int r = e / (RP / 4), q = e - r * (RP / 4);
                 const int p = row0 + r;
@@ -273,6 +296,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
             if (t0 + NTB < NT) __syncthreads();
         }
     }
+    PBN_WSTAMP(6);
 }
 
 template <typename T, int NF, int NT, int KW, bool KSPLIT>
@@ -353,6 +377,17 @@ int launch_t(const ConvArgs& a, int force_cfg, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef PBN_CONV_TIMING
+}  // namespace pbn
+// debug build only: the stamps of the last k_spconv_wave launch -> host
+extern "C" int pbn_wave_timing_read(unsigned long long* host) {
+    PBN_HIP_CHECK(hipDeviceSynchronize());
+    PBN_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(pbn::g_wave_timing), sizeof(unsigned long long) * (pbn::WT_BLOCKS * 64 + 8)));
+    return PBN_OK;
+}
+namespace pbn {
+#endif
 
 int launch_wave(const ConvArgs& a, int dtype, int force_cfg, hipStream_t stream) {
     switch (dtype) {
