@@ -547,7 +547,7 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, cons
     a.shift = shift; a.residual = residual; a.out = out_feat; a.ld_in = ld_in; a.ld_res = ld_res; a.ld_out = ld_out;
     a.K = n_offsets; a.vpo = vecs_per_offset; a.n_steps = n_steps; a.ntiles_total = cout_padded / 16; a.n_out = n_out;
     a.relu = relu;
-    a.ksplit = 1; a.partial = nullptr; a.n_out_pad = 0;
+    a.ksplit = 1; a.partial = nullptr; a.n_out_pad = 0; a.cg = 1; a.wmajor = 0;
     static const int dbg_env = getenv("PBN_CONV_DBG") ? atoi(getenv("PBN_CONV_DBG")) : 0;
     a.dbg = dbg_env;
     // coarse levels (and whatever PBN_CONV_FAMILY selects): the wave-autonomous family of spconv_wave.hip -- K split over

@@ -31,6 +31,7 @@ struct ConvArgs {
     float* partial;      // [ksplit][n_out_pad][ntiles_total*16]
     int n_out_pad;
     int cg;              // steps per barrier group (1..4)
+    int wmajor;          // wave family: weight-major block order (spconv_wave.hip map_block)
     int dbg;             // ablation switches for scripts/probe_conv_ablate.py (PBN_CONV_DBG); 0 in production
 };
 

@@ -24,7 +24,7 @@ namespace pbn {
 namespace {
 
 constexpr unsigned OOB = 0x80000000u;   // >= num_records of either resource: the load returns zeros
-constexpr unsigned UNIT_NONE = 0xffff0000u;   // step 0 (any valid weight address), offset 255 (no such offset): adds zeros
+constexpr unsigned UNIT_NONE = 0xffffu;        // a step past the end (n_steps <= 0xfffe): the unit loads nothing and adds zeros
 
 constexpr int MAX_DEPTH = 8;
 
@@ -41,9 +41,12 @@ __device__ unsigned long long g_wave_timing[WT_BLOCKS * 8 * 8 + 8];
 #endif
 // units in flight per wave.  Measured on the bench scene (scripts/probe_wave.py): 2 beats the deeper pipelines on every
 // level -- occupancy (registers) and the issue cost of the extra in-flight loads outweigh the latency they would hide
+#ifndef PBN_WAVE_DEPTH
+#define PBN_WAVE_DEPTH 2
+#endif
 constexpr int pipe_depth(int nf, int nt) {
     (void)nf; (void)nt;
-    return 2;
+    return PBN_WAVE_DEPTH;
 }
 
 template <int NF, int NT>
@@ -52,13 +55,12 @@ struct Stage {
     u32x4 x[NF];
 };
 
-// unit descriptor (built once per wave, kept in LDS): step | offset of lane group 0 << 16 | its channel vector << 24
-__device__ __forceinline__ unsigned pack_unit(int step, int ko, int cv0) {
-    return (unsigned)step | ((unsigned)ko << 16) | ((unsigned)cv0 << 24);
-}
-
-__device__ __forceinline__ u32x4 buf_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0));
+// Every vector-memory load of the main loop is issued from inline asm and waited for with a hand-counted s_waitcnt: loads
+// complete in issue order, so "unit i has landed" is a fixed count of the loads issued behind it.  (hipcc's own wait-count
+// insertion merges the scoreboard states of the loop entry and the back edge and drains the whole queue at the top of every
+// iteration -- measured: 940 cycles per unit with the builtin loads, i.e. no overlap at all.)
+__device__ __forceinline__ void buf_load_asm(u32x4& dst, const i32x4& rs, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");   // "+v": refilled in place, never through a copy
 }
 
 template <typename T>
@@ -78,35 +80,127 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, f32x4 v, int o
     store4<T>(reinterpret_cast<T*>(a.out) + (size_t)orow * a.ld_out + c0, v);
 }
 
+// channel tiles per LDS reduction round of a K-split workgroup: all of them when the KW partial tiles fit in 64 KiB
+constexpr int ksplit_round_tiles(int kw, int tm, int nt) {
+    return (kw * tm * nt * 64 <= 64 * 1024) ? nt : (nt < 2 ? nt : 2);
+}
+
+// blockIdx -> (row tile, channel-tile group).  Row-major launches keep contiguous row-tile ranges per XCD (neighbouring
+// tiles gather overlapping rows); WEIGHT-major launches (a.wmajor: the packed weights outweigh the input slab, i.e. the
+// coarse levels) give every XCD its own channel-tile groups instead, so that a weight byte enters ONE XCD's L2 instead of
+// all eight.  Both are bijections of a 1-D grid onto the (row tile, group) pairs they cover; blocks past the end exit.
+struct TileMap { int row_tile, group; bool valid; };
+__device__ __forceinline__ TileMap map_block(const ConvArgs& a, int n_row_tiles, int n_groups) {
+    TileMap m;
+    const int b = blockIdx.x;
+    if (!a.wmajor) {
+        m.group = b / n_row_tiles;
+        m.row_tile = xcd_tile(b - m.group * n_row_tiles, n_row_tiles);
+        m.valid = m.group < n_groups;
+        return m;
+    }
+    const int xcd = b & 7, idx = b >> 3;
+    if (n_groups >= 8) {                 // n_groups % 8 == 0 (checked at launch): XCD x owns groups x, x + 8, ...
+        const int gl = idx / n_row_tiles;
+        m.group = xcd + 8 * gl;
+        m.row_tile = idx - gl * n_row_tiles;
+        m.valid = m.group < n_groups;
+    } else {                             // n_groups in {1, 2, 4}: 8 / n_groups XCDs share a group and split its row tiles
+        const int share = 8 / n_groups;
+        m.group = xcd % n_groups;
+        m.row_tile = (xcd / n_groups) + share * idx;
+        m.valid = m.row_tile < n_row_tiles;
+    }
+    return m;
+}
+
 template <typename T, int NF, int NT, int KW, bool KSPLIT>
 __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     static_assert(Tr<T>::ELEMS * sizeof(T) == 16, "one gather vector is 16 bytes");
     constexpr int RW = NF * 16;                          // rows per wave
     constexpr int TM = KSPLIT ? RW : KW * RW;            // rows per workgroup
-    constexpr int NTB = NT < 2 ? NT : 2;                 // channel tiles per LDS reduction round (K-split)
+    constexpr int NTB = ksplit_round_tiles(KW, TM, NT);  // channel tiles per LDS reduction round (K-split)
     constexpr int TPB = KW * 64;
     constexpr int B = pipe_depth(NF, NT);                // units in flight per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = a.K;
     const int KS = K | 1;
     int* s_nbr = reinterpret_cast<int*>(smem);                                        // TM * KS
-    unsigned* s_units = reinterpret_cast<unsigned*>(s_nbr + ((TM * KS + 3) & ~3));    // KW * (n_steps + 2)
-    const int units_pitch = a.n_steps + 2 * MAX_DEPTH;
-    float* s_red = reinterpret_cast<float*>(s_units + ((KW * units_pitch + 3) & ~3)); // K-split: KW * TM * NTB*16 floats
+    // row-split: per-wave unit lists; K-split: units are computed (every step is visited), the space holds the epilogue
+    // constants (scale | shift of this workgroup's NT*16 channels) and the reduction buffer
+    unsigned* s_units = reinterpret_cast<unsigned*>(s_nbr + ((TM * KS + 3) & ~3));    // row-split: KW * (n_steps + 2 * MAX_DEPTH)
+    const int units_pitch = KSPLIT ? 0 : a.n_steps + 2 * MAX_DEPTH;
+    int* s_none = reinterpret_cast<int*>(s_units + ((KW * units_pitch + 3) & ~3));    // one word, -1: "no neighbour" for units past the end
+    float* s_ss = reinterpret_cast<float*>(s_none + 4);                               // K-split: 2 * NT*16 floats
+    float* s_red = s_ss + 2 * NT * 16;                                                // K-split: KW * TM * NTB*16 floats
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef PBN_CONV_TIMING
-    const int wt_blk = blockIdx.y * gridDim.x + blockIdx.x;
+    const int wt_blk = blockIdx.x;
     if (tid == 0 && wt_blk == 0) { g_wave_timing[WT_BLOCKS * 64] = gridDim.x; g_wave_timing[WT_BLOCKS * 64 + 1] = gridDim.y; }
 #endif
     PBN_WSTAMP(7);
     PBN_WSTAMP(0);
-    const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
-    const int row0 = xcd_tile(blockIdx.x, gridDim.x) * TM;
-    if (row0 >= n) return;
-    const int tile0 = blockIdx.y * NT;
+    const int n_groups = a.ntiles_total / NT;
+    const TileMap tm = map_block(a, (a.n_out + TM - 1) / TM, n_groups);
+    if (!tm.valid) return;
+    const int row0 = tm.row_tile * TM;
+    const int tile0 = tm.group * NT;
     const int g = lane >> 4, rl = lane & 15;
+
+    const unsigned long long in_addr = (unsigned long long)a.in, w_addr = (unsigned long long)a.w;
+    const i32x4 rs_in = {(int)(unsigned)in_addr, (int)(unsigned)(in_addr >> 32), (int)a.in_bytes, 0x00020000};
+    const i32x4 rs_w = {(int)(unsigned)w_addr, (int)(unsigned)(w_addr >> 32), (int)a.w_bytes, 0x00020000};
+    const unsigned ld_bytes = (unsigned)a.ld_in * (unsigned)sizeof(T);
+    const unsigned w_lane = (unsigned)lane * 16u;
+    const unsigned w_tile0 = (unsigned)tile0 * 1024u;
+    const unsigned w_step_bytes = (unsigned)a.ntiles_total * 1024u;
+    const int vpo = a.vpo;
+    const bool wide = (vpo & 3) == 0;
+    const int spo = wide ? (vpo >> 2) : 1;
+    const int vshift = (vpo == 2) ? 1 : 0;
+    const float inv_vpo = 1.0f / (float)vpo;
+    const int n_steps = a.n_steps;
+    unsigned* my_units = s_units + wave * units_pitch;
+
+    // step of this wave's unit i (>= n_steps: past the end, the unit adds zeros).  K-split: every step is visited, wave w
+    // takes steps w, w + KW, ...; row-split: the wave's list of populated steps in LDS
+    auto step_of = [&](int i) -> int {
+        if constexpr (KSPLIT) return i * KW + wave;
+        else return __builtin_amdgcn_readfirstlane((int)my_units[i]);
+    };
+    // the loads of one unit, branch-free (a branch in the loop body makes hipcc's wait-count insertion drain the queue at
+    // every join): NT weight fragments (wave-uniform address + lane * 16) ...
+    auto issue_w = [&](Stage<NF, NT>& st, int step) {
+        const unsigned w_soff = (unsigned)(step < n_steps ? step : 0) * w_step_bytes + w_tile0;
+#ifdef PBN_CONV_TIMING
+        if (a.dbg & 2) return;                                   // ablation: no weight loads
+        const unsigned w_lane = (a.dbg & 16) ? OOB : (unsigned)lane * 16u;   // ablation: weight loads out of range
+#endif
+#pragma unroll
+        for (int t = 0; t < NT; ++t) buf_load_asm(st.w[t], rs_w, w_lane, w_soff + (unsigned)t * 1024u);
+    };
+
+    Stage<NF, NT> st[B];
+#pragma unroll
+    for (int s = 0; s < B; ++s) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) st[s].w[t] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int f = 0; f < NF; ++f) st[s].x[f] = u32x4{0u, 0u, 0u, 0u};
+    }
+    if constexpr (KSPLIT) {
+        // epilogue constants of this workgroup's channels -> LDS (read back after the reduction)
+        if (tid < NT * 32) {
+            const int c = tile0 * 16 + (tid < NT * 16 ? tid : tid - NT * 16);
+            const float* src = tid < NT * 16 ? a.scale : a.shift;
+            s_ss[tid] = src ? src[c] : (tid < NT * 16 ? 1.0f : 0.0f);
+        }
+    }
+    const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
+    if (row0 >= n) return;
+    if (tid == 0) *s_none = -1;
 
     // ---- rulebook tile -> LDS ----
     if (a.nbr && !a.row_perm && row0 + TM <= n && KS == K && ((TM * K) & 3) == 0) {
@@ -129,42 +223,31 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     __syncthreads();
     PBN_WSTAMP(1);
 
-    // ---- which offsets are populated among this wave's rows (K <= 128: two ballots) ----
     const int wrow0 = KSPLIT ? 0 : wave * RW;
-    unsigned long long pop0, pop1;
+    int n_units;
     if constexpr (KSPLIT) {
         // coarse levels: 93-98 % of the (64-row tile, offset) pairs are populated (scripts/analyze_rulebook.py) -- visiting
-        // every offset costs a few per cent of MFMA work and takes the population scan (2 x RW LDS reads per lane) out of
-        // the prologue of a launch whose whole main loop is a few microseconds
-        pop0 = pop1 = ~0ull;
+        // every step costs a few per cent of MFMA work and takes the population scan and the unit list out of the prologue
+        // of a launch whose whole main loop is a few microseconds
+        n_units = a.n_steps > wave ? (a.n_steps - wave + KW - 1) / KW : 0;
     } else {
+        // ---- which offsets are populated among this wave's rows (K <= 128: two ballots) ----
         bool any0 = false, any1 = false;
         if (lane < K)
             for (int r = 0; r < RW; ++r) any0 |= s_nbr[(wrow0 + r) * KS + lane] >= 0;
         if (64 + lane < K)
             for (int r = 0; r < RW; ++r) any1 |= s_nbr[(wrow0 + r) * KS + 64 + lane] >= 0;
-        pop0 = __ballot(any0);
-        pop1 = __ballot(any1);
-    }
-    auto populated = [&](int k) -> bool { return ((k < 64 ? pop0 >> k : pop1 >> (k - 64)) & 1ull) != 0ull; };
-
-    // ---- this wave's unit list: populated steps, in order; K-split: every KW-th of them ----
-    const int vpo = a.vpo;
-    const bool wide = (vpo & 3) == 0;
-    const int spo = wide ? (vpo >> 2) : 1;
-    const int vshift = (vpo == 2) ? 1 : 0;
-    unsigned* my_units = s_units + wave * units_pitch;
-    int n_units;
-    {
-        int base = 0;   // populated steps seen so far (all waves of a K-split workgroup agree on it)
+        const unsigned long long pop0 = __ballot(any0), pop1 = __ballot(any1);
+        auto populated = [&](int k) -> bool { return ((k < 64 ? pop0 >> k : pop1 >> (k - 64)) & 1ull) != 0ull; };
+        // ---- this wave's unit list: populated steps, in order ----
+        int base = 0;
         for (int s0 = 0; s0 < a.n_steps; s0 += 64) {
             const int s = s0 + lane;
             bool ok = false;
-            int ko = 0, cv0 = 0;
+            int ko = 0;
             if (s < a.n_steps) {
                 if (wide) {
                     ko = s / spo;
-                    cv0 = (s - ko * spo) * 4;
                     ok = populated(ko);
                 } else {                      // a step spans 4 / vpo offsets; lane group g reads offset (4 s + g) >> vshift
                     ko = (s * 4) >> vshift;
@@ -174,20 +257,16 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
                 }
             }
             const unsigned long long m = __ballot(ok);
-            if (ok) {
-                const int pos = base + __popcll(m & ((1ULL << lane) - 1ULL));
-                if (!KSPLIT) my_units[pos] = pack_unit(s, ko, cv0);
-                else if (pos % KW == wave) my_units[pos / KW] = pack_unit(s, ko, cv0);
-            }
+            if (ok) my_units[base + __popcll(m & ((1ULL << lane) - 1ULL))] = (unsigned)s;
             base += __popcll(m);
         }
-        n_units = KSPLIT ? (base > wave ? (base - wave + KW - 1) / KW : 0) : base;
+        n_units = base;
         // sentinels: the pipeline below always has B units in flight and needs no tail handling
-        if (lane < 2 * B) my_units[n_units + lane] = UNIT_NONE;
+        if (lane < 2 * B + 2) my_units[n_units + lane] = UNIT_NONE;   // steps past the end
+        // the list is wave-private and a wave's LDS operations execute in order: the reads below follow the writes above
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    // the list is wave-private and a wave's LDS operations execute in order: the reads below follow the writes above
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     PBN_WSTAMP(2);
 
     f32x4 acc[NF][NT];
@@ -196,41 +275,38 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const __amdgpu_buffer_rsrc_t rs_in =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)a.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)a.w_bytes, 0x00020000);
-    const unsigned ld_bytes = (unsigned)a.ld_in * (unsigned)sizeof(T);
-    const unsigned w_lane = (unsigned)lane * 16u;
-    const unsigned w_tile0 = (unsigned)tile0 * 1024u;
-    const unsigned w_step_bytes = (unsigned)a.ntiles_total * 1024u;
     const int my_row = wrow0 + rl;
-
-    // all loads of one unit: NT weight fragments (wave-uniform address + lane * 16) and NF gathered row fragments (one
-    // 16-byte vector of one neighbour row per lane; no neighbour / past the last offset -> out-of-range offset -> zeros)
-    auto issue = [&](Stage<NF, NT>& st, int i) {
-        const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((int)my_units[i]);
-        const unsigned step = u & 0xffffu, ko0 = (u >> 16) & 0xffu, cv0 = u >> 24;
-        int ko, cv;
-        if (wide) {
-            ko = (int)ko0;
-            cv = (int)cv0 + g;
-        } else {
-            const int v = (int)step * 4 + g;
-            ko = ko0 == 0xffu ? 255 : (v >> vshift);
-            cv = v & (vpo - 1);
-        }
-        const unsigned w_soff = step * w_step_bytes + w_tile0;
+    // ... and NF gathered row fragments (one 16-byte vector of one neighbour row per lane; no neighbour / past the last
+    // offset -> out-of-range offset -> zeros)
+    // The rulebook entries of a unit are read from LDS one unit AHEAD of its gathers (Idx travels in registers across one
+    // iteration): the LDS round trips are off the issue path of the loads.
+    struct Idx { int src[NF]; unsigned cvb; };
+    auto fetch_idx = [&](int step) -> Idx {
+        // lane group g reads vector v = 4 step + g of the flattened (offset, channel) axis: offset v / vpo, channel vector
+        // v % vpo (float reciprocal: exact here); past the last offset or the last step -> the "-1" word -> zeros
+        const int v = step * 4 + g;
+        const int ko = (int)(((float)v + 0.5f) * inv_vpo);
+        const bool live = step < n_steps && ko < K;
+        Idx ix;
+        ix.cvb = (unsigned)(v - ko * vpo) * 16u;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) st.w[t] = buf_load(rs_w, w_lane, w_soff + (unsigned)t * 1024u);
+        for (int f = 0; f < NF; ++f) ix.src[f] = *(live ? s_nbr + (my_row + f * 16) * KS + ko : s_none);
+        return ix;
+    };
+    auto issue_x = [&](Stage<NF, NT>& st, const Idx& ix) {
+#ifdef PBN_CONV_TIMING
+        if (a.dbg & 1) return;                                   // ablation: no row gathers
+#endif
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const int src = ko < K ? s_nbr[(my_row + f * 16) * KS + ko] : -1;
-            const unsigned voff = src >= 0 ? (unsigned)src * ld_bytes + (unsigned)cv * 16u : OOB;
-            st.x[f] = buf_load(rs_in, voff, 0u);
+            const unsigned voff = ix.src[f] >= 0 ? (unsigned)ix.src[f] * ld_bytes + ix.cvb : OOB;
+            buf_load_asm(st.x[f], rs_in, voff, 0u);
         }
     };
     auto compute = [&](const Stage<NF, NT>& st) {
+#ifdef PBN_CONV_TIMING
+        if (a.dbg & 4) return;                                   // ablation: no MFMAs
+#endif
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -238,21 +314,59 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     };
 
     {
-        // B units in flight: a unit's registers are refilled with the unit B positions ahead as soon as its MFMAs are
-        // issued (loads retire in order, so the compiler's counted vmcnt waits are exact); a coarse-level wave-unit is
-        // ~100 cycles of MFMA against ~1500 cycles of L2 latency, hence the depth
-        Stage<NF, NT> st[B];
+        // B units in flight: a unit's registers are refilled with the unit B positions ahead right behind its own MFMAs.
+        // Issue order = unit order (weights, then rows), so when unit i is consumed the loads behind it are exactly those of
+        // units i+1 .. i+B-1: wait for vmcnt((B-1) * (NT+NF)).  The wait names the unit's registers so that their readers
+        // are ordered behind it.
+        constexpr int BEHIND = (B - 1) * (NT + NF);
+        auto wait_unit = [&](Stage<NF, NT>& u) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(u.w[0]) : "n"(BEHIND));
 #pragma unroll
-        for (int s = 0; s < B; ++s) issue(st[s], s);
+            for (int t = 1; t < NT; ++t) asm volatile("" : "+v"(u.w[t]));
+#pragma unroll
+            for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(u.x[f]));
+        };
+        // issue slot k: the loads of unit k (its step and rulebook entries were fetched during slot k - 1), then the
+        // fetches for slot k + 1
+        int step = step_of(0);
+        Idx ix = fetch_idx(step);
+        int raw_next = 0;
+        if constexpr (!KSPLIT) raw_next = (int)my_units[1];
+        auto slot = [&](Stage<NF, NT>& u, int k) {
+            issue_w(u, step);
+            issue_x(u, ix);
+            if constexpr (KSPLIT) {
+                step = step_of(k + 1);
+            } else {
+                step = __builtin_amdgcn_readfirstlane(raw_next);
+                raw_next = (int)my_units[k + 2];
+            }
+            ix = fetch_idx(step);
+        };
+#pragma unroll
+        for (int s = 0; s < B; ++s) slot(st[s], s);
         PBN_WSTAMP(3);
         for (int i = 0; i < n_units; i += B) {
 #pragma unroll
             for (int s = 0; s < B; ++s) {
+                wait_unit(st[s]);
                 compute(st[s]);
-                issue(st[s], i + B + s);
+                __builtin_amdgcn_sched_barrier(0);     // the refill stays behind the unit's own MFMAs
+                slot(st[s], i + B + s);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // the trailing issues read sentinels: harmless loads that are never consumed
+        // the trailing issues were units past the end; drain them.  The wait NAMES every stage register: they stay allocated
+        // up to here (otherwise the epilogue's address arithmetic is scheduled into them above the wait and a landing
+        // load overwrites it -- seen as run-to-run different rows)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < B; ++s) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(st[s].w[t]));
+#pragma unroll
+            for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(st[s].x[f]));
+        }
     }
     PBN_WSTAMP(4);
 
@@ -268,6 +382,8 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     } else {
         // fixed-order sum of the KW partial tiles through LDS, NTB channel tiles per round, then the epilogue
         constexpr int RP = NTB * 16;   // floats per row per round
+        T* out = reinterpret_cast<T*>(a.out);
+        const T* res = reinterpret_cast<const T*>(a.residual);
 #pragma unroll
         for (int t0 = 0; t0 < NT; t0 += NTB) {
 #pragma unroll
@@ -284,14 +400,29 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
                 const int r = e / (RP / 4), q = e - r * (RP / 4);
                 const int p = row0 + r;
                 if (p >= n) continue;
+                const int orow = a.row_perm ? a.row_perm[p] : p;
+                const int cl = t0 * 16 + q * 4;          // channel within this workgroup's NT*16
+                f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (res) rv = load4<T>(res + (size_t)orow * a.ld_res + tile0 * 16 + cl);   // in flight under the LDS sum
                 f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int w = 0; w < KW; ++w) {
                     const float4 s = *reinterpret_cast<const float4*>(s_red + ((size_t)(w * TM + r) * RP + q * 4));
                     v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
                 }
-                const int orow = a.row_perm ? a.row_perm[p] : p;
-                epilogue_store<T>(a, v, orow, (tile0 + t0) * 16 + q * 4);
+                if (a.scale) {
+                    const float4 sc = *reinterpret_cast<const float4*>(s_ss + cl);
+                    v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+                }
+                if (a.shift) {
+                    const float4 sh = *reinterpret_cast<const float4*>(s_ss + NT * 16 + cl);
+                    v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+                }
+                v += rv;
+                if (a.relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                store4<T>(out + (size_t)orow * a.ld_out + tile0 * 16 + cl, v);
             }
             if (t0 + NTB < NT) __syncthreads();
         }
@@ -300,20 +431,27 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
 }
 
 template <typename T, int NF, int NT, int KW, bool KSPLIT>
-int launch_cfg(const ConvArgs& a, hipStream_t stream) {
+int launch_cfg(ConvArgs a, hipStream_t stream) {
     constexpr int RW = NF * 16;
     constexpr int TM = KSPLIT ? RW : KW * RW;
-    constexpr int NTB = NT < 2 ? NT : 2;
+    constexpr int NTB = ksplit_round_tiles(KW, TM, NT);
     if (a.ntiles_total % NT) return PBN_ERR_UNSUPPORTED;
     const int KS = a.K | 1;
-    size_t lds = sizeof(int) * (size_t)((TM * KS + 3) & ~3) +
-                 sizeof(unsigned) * (size_t)((KW * (a.n_steps + 2 * MAX_DEPTH) + 3) & ~3);
-    if (KSPLIT) lds += sizeof(float) * (size_t)KW * TM * NTB * 16;
+    size_t lds = sizeof(int) * (size_t)((TM * KS + 3) & ~3);
+    if (KSPLIT) lds += 16 + sizeof(float) * ((size_t)2 * NT * 16 + (size_t)KW * TM * NTB * 16);
+    else lds += 16 + sizeof(unsigned) * (size_t)((KW * (a.n_steps + 2 * MAX_DEPTH) + 3) & ~3);
     if (lds > 160 * 1024 || a.K > 128 || a.n_steps > 0xfffe) return PBN_ERR_UNSUPPORTED;
     auto kern = k_spconv_wave<T, NF, NT, KW, KSPLIT>;
     if (lds > 64 * 1024)
         PBN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(cdiv(a.n_out, TM), a.ntiles_total / NT), dim3(KW * 64), lds, stream, a);
+    const int row_tiles = cdiv(a.n_out, TM), groups = a.ntiles_total / NT;
+    // weight-major block order (see map_block) where the packed weights outweigh the input slab: coarse levels
+    static const int wmajor_env = getenv("PBN_WAVE_WMAJOR") ? atoi(getenv("PBN_WAVE_WMAJOR")) : 2;   // 0 off, 1 always, 2 by size
+    const bool shape_ok = groups >= 8 ? (groups % 8 == 0) : (groups == 1 || groups == 2 || groups == 4);
+    a.wmajor = (wmajor_env == 1 || (wmajor_env == 2 && a.w_bytes > a.in_bytes)) && shape_ok && groups > 1 ? 1 : 0;
+    int blocks = row_tiles * groups;
+    if (a.wmajor && groups < 8) blocks = 8 * cdiv(row_tiles, 8 / groups);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(KW * 64), lds, stream, a);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
