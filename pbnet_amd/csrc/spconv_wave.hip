@@ -44,6 +44,15 @@ __device__ unsigned long long g_wave_timing[WT_BLOCKS * 8 * 8 + 8];
 #ifndef PBN_WAVE_DEPTH
 #define PBN_WAVE_DEPTH 2
 #endif
+// Row gathers in a QUAD-COALESCED lane order: lane 4 r + c fetches 16-byte chunk c of row r of the fragment, so the four
+// lanes of a quad read one contiguous 64-byte piece of one row (16 cache-line accesses per wave-load); the MFMA operand
+// order (lane 16 g + r holds chunk g of row r: consecutive lanes = consecutive ROWS, 64 line accesses per wave-load) is
+// restored on the way in by four ds_bpermute_b32 per fragment (LDS crossbar, no LDS memory).  scripts/micro/
+// gather_layout.hip: an L2-resident gather costs 62 cycles of the CU's vector-memory path per wave-load in operand order, 32
+// quad-coalesced (a contiguous 1 KiB load: 30).
+#ifndef PBN_WAVE_XCOAL
+#define PBN_WAVE_XCOAL 1
+#endif
 constexpr int pipe_depth(int nf, int nt) {
     (void)nf; (void)nt;
     return PBN_WAVE_DEPTH;
@@ -275,7 +284,9 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int my_row = wrow0 + rl;
+    const int my_row = wrow0 + (PBN_WAVE_XCOAL ? (lane >> 2) : rl);     // the row this lane gathers for (per fragment)
+    const int my_chunk = PBN_WAVE_XCOAL ? (lane & 3) : g;                 // ... and its 16-byte chunk of the step
+    const int xpose_addr = (4 * (lane & 15) + (lane >> 4)) * 4;          // operand-order lane 16 g + r pulls from lane 4 r + g
     // ... and NF gathered row fragments (one 16-byte vector of one neighbour row per lane; no neighbour / past the last
     // offset -> out-of-range offset -> zeros)
     // The rulebook entries of a unit are read from LDS one unit AHEAD of its gathers (Idx travels in registers across one
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     auto fetch_idx = [&](int step) -> Idx {
         // lane group g reads vector v = 4 step + g of the flattened (offset, channel) axis: offset v / vpo, channel vector
         // v % vpo (float reciprocal: exact here); past the last offset or the last step -> the "-1" word -> zeros
-        const int v = step * 4 + g;
+        const int v = step * 4 + my_chunk;
         const int ko = (int)(((float)v + 0.5f) * inv_vpo);
         const bool live = step < n_steps && ko < K;
         Idx ix;
@@ -307,10 +318,22 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
 #ifdef PBN_CONV_TIMING
         if (a.dbg & 4) return;                                   // ablation: no MFMAs
 #endif
+#if PBN_WAVE_XCOAL
+        u32x4 xo[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) xo[f][d] = (unsigned)__builtin_amdgcn_ds_bpermute(xpose_addr, (int)st.x[f][d]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) mfma_step<T>(st.w[t], xo[f], acc[f][t]);
+#else
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int f = 0; f < NF; ++f) mfma_step<T>(st.w[t], st.x[f], acc[f][t]);
+#endif
     };
 
     {
@@ -541,14 +564,15 @@ int launch_wave(const ConvArgs& a, int dtype, int force_cfg, hipStream_t stream)
 // layers (1408: L3 256->256 19.6 us against 26.3 for 1404; 43.6 against 33.6 alone) -- in the real pipeline, where the
 // other streams run OTHER layers, a process-wide switch to those tiles measured 2-3 % slower (274-278 against 283-285
 // scenes/s), so the choice below stays the one-scene one.
-// Measured crossover (scripts/probe_wave.py, HIP-graph replay): the K-split wave kernel is level with or ahead of the
-// workgroup-tile kernel + its split-K reduce launch up to ~6e9 dense MACs (rows x K x C_in x C_out) on levels below 20 k
-// rows, and behind it above (L3 384->256, L2 128->128) and on every wide level.
+// Measured crossover (scripts/probe_wave.py, HIP-graph replay, round 3 after the hand-counted main loop and the
+// quad-coalesced gathers): the K-split wave kernel is ahead of the workgroup-tile kernel + its split-K reduce launch on every
+// level below 20 k rows up to ~1e10 dense MACs (rows x K x C_in x C_out; L3 384->256 30.3 against 40.2 us, L2 128->128 28.8
+// against 33.8), and behind it on the wide levels (L1 96->96 48.5 against 38.0, L0 96->96 116 against 74.5).
 bool wave_family_wanted(const ConvArgs& a, int dtype) {
     (void)dtype;
     static const int fam = getenv("PBN_CONV_FAMILY") ? atoi(getenv("PBN_CONV_FAMILY")) : 2;
     static const int max_rows = getenv("PBN_WAVE_MAX_ROWS") ? atoi(getenv("PBN_WAVE_MAX_ROWS")) : 20000;
-    static const double max_macs = getenv("PBN_WAVE_MAX_GMACS") ? atof(getenv("PBN_WAVE_MAX_GMACS")) * 1e9 : 6.3e9;
+    static const double max_macs = getenv("PBN_WAVE_MAX_GMACS") ? atof(getenv("PBN_WAVE_MAX_GMACS")) * 1e9 : 1.0e10;
     if (a.K > 128) return false;
     if (fam == 0) return false;
     if (fam == 1) return true;

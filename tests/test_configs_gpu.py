@@ -177,7 +177,9 @@ def test_c3_bf16_training_step_at_scene_size_vs_fp32():
       * every loss term within 2e-2 of the fp32 step (observed 4e-5) and the same proposals;
       * parameters NEXT TO a loss (mask head, the mask U-Net's last block, the last layer of the score head) have
         gradients aligned with fp32: cosine >= 0.98, norm ratio within 10 %;
-      * every other gradient is finite with a norm within 3x of fp32.  Their DIRECTION is not part of the contract: with
+      * every other gradient is finite with a norm within 3x of fp32 (tensors of >= 16 elements: the gradient of a
+        one-element parameter -- a PReLU slope behind the pool -- is ONE signed sum over all rows, it cancels like a
+        direction does and is only required to be finite).  Their DIRECTION is not part of the contract: with
         random-init weights the backward signal crosses a global MAX pool (one winning row per proposal and channel:
         bf16 rounding changes the winner) and ~100 train-mode BatchNorm + ReLU layers, and decorrelates on the way
         (observed cosine 0.81 two layers behind the pool, ~0.06 inside the 34C networks).  That bf16 backward itself is
@@ -203,10 +205,10 @@ def test_c3_bf16_training_step_at_scene_size_vs_fp32():
         a, b = g16[n_].reshape(-1).double(), g32[n_].reshape(-1).double()
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
         ratio = float(a.norm() / (b.norm() + 1e-30))
-        rows.append((n_, cos, ratio, float(b.norm())))
+        rows.append((n_, cos, ratio, float(b.norm()), a.numel()))
     for n_ in names:
         r = next(r for r in rows if r[0] == n_)
-        print("  %-40s cos %.5f  |g16|/|g32| %.4f  |g32| %.3e" % r)
+        print("  %-40s cos %.5f  |g16|/|g32| %.4f  |g32| %.3e" % r[:4])
     import collections
     by_net = collections.defaultdict(list)
     for r in rows:
@@ -219,5 +221,6 @@ def test_c3_bf16_training_step_at_scene_size_vs_fp32():
     assert len(near) >= 10
     bad = [r for r in near if not (r[1] >= 0.98 and 0.9 <= r[2] <= 1.1)]
     assert not bad, bad
-    wild = [r for r in rows if not (np.isfinite(r[1]) and 0.33 <= r[2] <= 3.0) and r[3] > 1e-6]      # norm within 3x
+    wild = [r for r in rows if not (np.isfinite(r[1]) and 0.33 <= r[2] <= 3.0) and r[3] > 1e-6 and r[4] >= 16]   # norm within 3x
     assert not wild, wild
+    assert all(np.isfinite(r[2]) for r in rows)
