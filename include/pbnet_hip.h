@@ -471,6 +471,10 @@ int pbn_coords_prepare_dev(const int32_t* coords, const int32_t* n_dev, int n_ca
                            size_t arena_bytes, const pbn_prepare_layout* layout, pbn_stream_t stream);
 int pbn_coords_prepare(const int32_t* coords, int n, int want_k5, int x_fastest, void* arena, size_t arena_bytes,
                        const pbn_prepare_layout* layout, pbn_stream_t stream);
+/* The same contract through the hash-table pipeline of pbn_coords_build (one table per level, values renumbered) instead of
+ * the sorted, hash-free one: the cross-check of csrc/pyramid.hip (every output array must be equal); n_dev may be null. */
+int pbn_coords_prepare_hash(const int32_t* coords, const int32_t* n_dev, int n_cap, int want_k5, int x_fastest, void* arena,
+                            size_t arena_bytes, const pbn_prepare_layout* layout, pbn_stream_t stream);
 
 /* Z-order keys (batch-major, then bit-interleaved x, y, z) of coordinate rows; rows at or beyond *n_dev get the largest
  * key.  Sorting rows by this key turns every run of consecutive rows into a compact spatial block: convolution tiles

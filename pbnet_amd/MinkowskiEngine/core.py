@@ -18,6 +18,9 @@ def _i32(n, dev, fill=None):
 
 
 _OFFSETS = {}
+_RANGE_ERROR = ("coordinates cannot be indexed: batch must be in [0,65534], x/y/z in [-32768,32767], and the bounding box of one "
+                "call must fit 44 Z-order key bits (3 x bits of the largest extent + bits of the batch range); also raised when a "
+                "coordinate table was found full or corrupted")
 
 
 def _device_offsets(kernel_size, stride, device):
@@ -67,8 +70,8 @@ class _Pyramid(object):
         return self.arena.data_ptr() + offset
 
     def set_counts(self, counts):
-        if counts[0] < 0:
-            raise ValueError("coordinate out of range: batch must be in [0,65534], x/y/z in [-32768,32767]")
+        if min(counts) < 0:
+            raise ValueError(_RANGE_ERROR)
         self.n = [int(c) for c in counts]
 
     def finalize(self):
@@ -215,8 +218,6 @@ class CoordinateManager(object):
             arena, P = self._native
             pyr = self._sorted.pyramid
             counts = pyr.counts_dev.tolist()                                           # the one host read
-            if counts[0] < 0:
-                raise ValueError("coordinate out of range: batch must be in [0,65534], x/y/z in [-32768,32767]")
             pyr.set_counts(counts)
             n1 = self._n1 = int(counts[0])
             n = self.n_input
@@ -229,8 +230,8 @@ class CoordinateManager(object):
             return
         pending = [p for p in (self._plain, self._sorted.pyramid if self._sorted else None) if p is not None and p.n is None]
         counts = torch.cat([self._count] + [p.counts_dev for p in pending]).tolist()   # the one host read
-        if counts[0] < 0:
-            raise ValueError("coordinate out of range: batch must be in [0,65534], x/y/z in [-32768,32767]")
+        if min(counts) < 0:
+            raise ValueError(_RANGE_ERROR)
         self._n1 = int(counts[0])
         for i, p in enumerate(pending):
             p.set_counts(counts[1 + 5 * i:6 + 5 * i])

@@ -119,6 +119,7 @@ SIGNATURES = {
     "pbn_coords_prepare_bytes": (c_size, [c_int, c_int, ctypes.POINTER(PrepareLayout)]),
     "pbn_coords_prepare": (c_int, [c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(PrepareLayout), c_vp]),
     "pbn_coords_prepare_dev": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(PrepareLayout), c_vp]),
+    "pbn_coords_prepare_hash": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(PrepareLayout), c_vp]),
     "pbn_unet_forward_dev": (c_int, [ctypes.POINTER(UnetOp), c_int, ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32),
                                      c_i32p, c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp,
                                      ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_vp, c_size, c_int,

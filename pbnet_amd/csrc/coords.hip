@@ -11,56 +11,10 @@
 // capacity = pow2 >= 2n.  Values: smallest inserting row (atomicMin) => deterministic "first occurrence".
 // Row counts that depend on the data stay on the DEVICE (n_out pointers); kernels take an upper bound for the grid
 // and read the real count, so a whole coordinate pyramid is built without a host round trip.
-#include "pbn_common.h"
+#include "coords_dev.h"
 
 namespace pbn {
 namespace {
-
-constexpr int TPB = 256;
-constexpr unsigned long long EMPTY_KEY = ~0ULL;
-
-__device__ __forceinline__ bool in_range(int b, int x, int y, int z) {
-    return b >= 0 && b < 65535 && x >= -32768 && x <= 32767 && y >= -32768 && y <= 32767 && z >= -32768 && z <= 32767;
-}
-
-__device__ __forceinline__ unsigned long long pack4(int b, int x, int y, int z) {
-    return ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)(unsigned)((x + 32768) & 0xffff) << 32) |
-           ((unsigned long long)(unsigned)((y + 32768) & 0xffff) << 16) | (unsigned long long)(unsigned)((z + 32768) & 0xffff);
-}
-
-__device__ __forceinline__ int floor_div(int a, int s) {  // s > 0
-    int q = a / s;
-    return (a % s != 0 && a < 0) ? q - 1 : q;
-}
-
-__device__ __forceinline__ int table_insert_min(unsigned long long* __restrict__ keys, int* __restrict__ vals,
-                                                unsigned mask, unsigned long long key, int row) {
-    unsigned h = hash64(key) & mask;
-    while (true) {
-        unsigned long long prev = atomicCAS(&keys[h], EMPTY_KEY, key);
-        if (prev == EMPTY_KEY || prev == key) break;
-        h = (h + 1) & mask;
-    }
-    atomicMin(&vals[h], row);
-    return (int)h;
-}
-
-__device__ __forceinline__ int table_find(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
-                                          unsigned mask, unsigned long long key) {
-    unsigned h = hash64(key) & mask;
-    while (true) {
-        const unsigned long long k = keys[h];
-        if (k == key) return vals[h];
-        if (k == EMPTY_KEY) return -1;
-        h = (h + 1) & mask;
-    }
-}
-
-__device__ __forceinline__ int real_n(const int* n_dev, int n_max) {
-    if (!n_dev) return n_max;
-    const int v = *n_dev;
-    return v < n_max ? v : n_max;
-}
 
 // ---- unique ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void k_insert_rows(const int* __restrict__ coords, const int* n_dev, int n_max,
@@ -69,23 +23,13 @@ __global__ __launch_bounds__(TPB) void k_insert_rows(const int* __restrict__ coo
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= real_n(n_dev, n_max)) return;
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
-    if (!in_range(c.x, c.y, c.z, c.w)) atomicOr(status, 1);
-    slot_of_row[i] = table_insert_min(keys, vals, mask, pack4(c.x, c.y, c.z, c.w), i);
+    if (!in_range(c.x, c.y, c.z, c.w)) atomicOr(status, PBN_STATUS_RANGE);
+    slot_of_row[i] = table_insert_min(keys, vals, mask, pack4(c.x, c.y, c.z, c.w), i, status);
 }
 
 // "row i is the first occurrence of its key": the slot's value is the smallest inserting row
 __device__ __forceinline__ int first_flag(const int* __restrict__ slot_of_row, const int* __restrict__ vals, int i, int n) {
     return (i < n && vals[slot_of_row[i]] == i) ? 1 : 0;
-}
-
-__device__ __forceinline__ int wave_incl_scan_i(int v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
 }
 
 // Survivor numbering = exclusive scan of the first-occurrence flags, in two launches instead of flags + 3-launch scan:
@@ -188,13 +132,13 @@ __global__ __launch_bounds__(TPB) void k_unique_write(const int* __restrict__ co
 __global__ __launch_bounds__(TPB) void k_insert_parents(const int* __restrict__ coords, const int* n_dev, int n_max,
                                                        int stride_out, unsigned long long* __restrict__ keys,
                                                        int* __restrict__ vals, unsigned mask,
-                                                       int* __restrict__ slot_of_row) {
+                                                       int* __restrict__ slot_of_row, int* __restrict__ status) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= real_n(n_dev, n_max)) return;
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
     const int px = floor_div(c.y, stride_out) * stride_out, py = floor_div(c.z, stride_out) * stride_out,
               pz = floor_div(c.w, stride_out) * stride_out;
-    slot_of_row[i] = table_insert_min(keys, vals, mask, pack4(c.x, px, py, pz), i);
+    slot_of_row[i] = table_insert_min(keys, vals, mask, pack4(c.x, px, py, pz), i, status);
 }
 
 // coarse coords (first-occurrence order), child -> (parent row, k), 8-way child table of the k=2,s=2 convolution,
@@ -328,10 +272,22 @@ int coords_unique_impl(const int32_t* coords, const int32_t* n_dev, int n_max, u
     return PBN_OK;
 }
 
+// survivor numbering over first-occurrence flags (the two launches of coords_unique_impl), for pyramid.hip
+int coords_number_first(const int32_t* slot_of_row, const int32_t* table_vals, const int32_t* n_dev, int n_max, int32_t* scan_tmp,
+                        int32_t* newid, int32_t* first_row, int32_t* n_out, const int32_t* status, hipStream_t stream) {
+    if (n_max <= 0) return PBN_OK;
+    const int nsb = cdiv(n_max, SCAN_TILE);
+    hipLaunchKernelGGL(k_flag_block_sums, dim3(nsb), dim3(SCAN_THREADS), 0, stream, slot_of_row, table_vals, n_dev, n_max, scan_tmp);
+    hipLaunchKernelGGL(k_flag_number, dim3(nsb), dim3(SCAN_THREADS), 0, stream, slot_of_row, table_vals, n_dev, n_max, scan_tmp,
+                       newid, first_row, n_out, status);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
 int coords_stride_impl(const int32_t* fine_coords, const int32_t* n_fine_dev, int n_fine_max, int stride_out,
                        uint64_t* table_keys, int32_t* table_vals, int capacity, int32_t* coarse_coords,
                        int32_t* parent_row, int32_t* child_k, int32_t* nbr_down, int32_t* nbr_up, int32_t* n_coarse,
-                       void* workspace, size_t workspace_bytes, bool clear, hipStream_t stream) {
+                       void* workspace, size_t workspace_bytes, int32_t* status, bool clear, hipStream_t stream) {
     if (n_fine_max < 0 || stride_out < 2 || (stride_out & 1) || capacity < 1024 || (capacity & (capacity - 1)) ||
         (long long)capacity < 2LL * n_fine_max || !n_coarse || !table_keys || !table_vals)
         return PBN_ERR_ARG;
@@ -345,14 +301,18 @@ int coords_stride_impl(const int32_t* fine_coords, const int32_t* n_fine_dev, in
     CoordWs w;
     if (!carve_ws(workspace, workspace_bytes, n_fine_max, w)) return PBN_ERR_WORKSPACE;
     if (clear) { const int frc_ = fill_bytes(nbr_down, 0xff, sizeof(int) * 8 * (size_t)n_fine_max, stream); if (frc_ != PBN_OK) return frc_; }
+    if (!status) {
+        status = w.status;
+        { const int frc_ = fill_bytes(status, 0, sizeof(int) * 4, stream); if (frc_ != PBN_OK) return frc_; }
+    }
     const int nb = cdiv(n_fine_max, TPB), nsb = cdiv(n_fine_max, SCAN_TILE);
     const unsigned mask = (unsigned)capacity - 1;
     hipLaunchKernelGGL(k_insert_parents, dim3(nb), dim3(TPB), 0, stream, fine_coords, n_fine_dev, n_fine_max, stride_out,
-                       (unsigned long long*)table_keys, table_vals, mask, w.slot_of_row);
+                       (unsigned long long*)table_keys, table_vals, mask, w.slot_of_row, status);
     hipLaunchKernelGGL(k_flag_block_sums, dim3(nsb), dim3(SCAN_THREADS), 0, stream, w.slot_of_row, table_vals, n_fine_dev,
                        n_fine_max, w.scan_tmp);
     hipLaunchKernelGGL(k_flag_number, dim3(nsb), dim3(SCAN_THREADS), 0, stream, w.slot_of_row, table_vals, n_fine_dev,
-                       n_fine_max, w.scan_tmp, w.newid, w.first_row, n_coarse, (const int*)nullptr);
+                       n_fine_max, w.scan_tmp, w.newid, w.first_row, n_coarse, (const int*)status);
     hipLaunchKernelGGL(k_stride_write, dim3(nb), dim3(TPB), 0, stream, fine_coords, n_fine_dev, n_fine_max, stride_out,
                        w.slot_of_row, w.first_row, w.newid, table_vals, coarse_coords, parent_row, child_k, nbr_down,
                        nbr_up);
@@ -375,7 +335,7 @@ extern "C" int pbn_coords_stride(const int32_t* fine_coords, const int32_t* n_fi
                                  void* workspace, size_t workspace_bytes, pbn_stream_t stream_) {
     return coords_stride_impl(fine_coords, n_fine_dev, n_fine_max, stride_out, table_keys, table_vals, capacity,
                               coarse_coords, parent_row, child_k, nbr_down, nullptr, n_coarse, workspace, workspace_bytes,
-                              true, (hipStream_t)stream_);
+                              nullptr, true, (hipStream_t)stream_);
 }
 
 extern "C" int pbn_kernel_map(const int32_t* out_coords, const int32_t* n_out_dev, int n_out_max, const int32_t* offsets,
@@ -494,15 +454,6 @@ extern "C" int pbn_kernel_map_cube(const int32_t* out_coords, const int32_t* n_o
 // consecutive rows a compact spatial block, which is what the convolution tiles and their L2 locality want -------------
 namespace pbn {
 namespace {
-__device__ __forceinline__ unsigned long long spread3(unsigned v) {  // 16 bits -> every third bit of 48
-    unsigned long long x = v & 0xffffu;
-    x = (x | (x << 32)) & 0x00ff00000000ffffULL;
-    x = (x | (x << 16)) & 0x00ff0000ff0000ffULL;
-    x = (x | (x << 8)) & 0xf00f00f00f00f00fULL;
-    x = (x | (x << 4)) & 0x30c30c30c30c30c3ULL;
-    x = (x | (x << 2)) & 0x9249249249249249ULL;
-    return x;
-}
 __global__ __launch_bounds__(TPB) void k_morton_keys(const int* __restrict__ coords, const int* n_dev, int n_max,
                                                     long long* __restrict__ keys) {
     const int i = blockIdx.x * TPB + threadIdx.x;
@@ -533,7 +484,7 @@ namespace {
 __global__ __launch_bounds__(TPB) void k_insert_identity(const int* __restrict__ coords, const int* n_dev, int n_max,
                                                         unsigned long long* __restrict__ keys, int* __restrict__ vals,
                                                         unsigned mask, int* __restrict__ out_coords,
-                                                        int* __restrict__ n_out) {
+                                                        int* __restrict__ n_out, int* __restrict__ status) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     const int n = real_n(n_dev, n_max);
     if (i == 0) *n_out = n_dev ? *n_dev : n_max;      // keeps a -1 (range error) visible
@@ -542,8 +493,11 @@ __global__ __launch_bounds__(TPB) void k_insert_identity(const int* __restrict__
     reinterpret_cast<int4*>(out_coords)[i] = c;
     unsigned h = hash64(pack4(c.x, c.y, c.z, c.w)) & mask;
     const unsigned long long key = pack4(c.x, c.y, c.z, c.w);
-    while (atomicCAS(&keys[h], EMPTY_KEY, key) != EMPTY_KEY) h = (h + 1) & mask;
-    vals[h] = i;
+    for (unsigned probes = 0; probes <= mask; ++probes) {
+        if (atomicCAS(&keys[h], EMPTY_KEY, key) == EMPTY_KEY) { vals[h] = i; return; }
+        h = (h + 1) & mask;
+    }
+    if (status) atomicOr(status, PBN_STATUS_TABLE_FULL);
 }
 
 __global__ __launch_bounds__(TPB) void k_morton_iota(const int* __restrict__ coords, const int* n_dev, int n_max,
@@ -576,10 +530,10 @@ __global__ __launch_bounds__(TPB) void k_apply_perm(const int* __restrict__ ucoo
 }  // namespace
 
 int coords_insert_identity(const int32_t* coords, const int32_t* n_dev, int n_max, uint64_t* keys, int32_t* vals,
-                           int capacity, int32_t* out_coords, int32_t* n_out, hipStream_t stream) {
+                           int capacity, int32_t* out_coords, int32_t* n_out, int32_t* status, hipStream_t stream) {
     if (n_max <= 0) return PBN_OK;
     hipLaunchKernelGGL(k_insert_identity, dim3(cdiv(n_max, TPB)), dim3(TPB), 0, stream, coords, n_dev, n_max,
-                       (unsigned long long*)keys, vals, (unsigned)capacity - 1, out_coords, n_out);
+                       (unsigned long long*)keys, vals, (unsigned)capacity - 1, out_coords, n_out, status);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }

@@ -6,6 +6,7 @@
 //                       MinkUNetBase.forward (/root/reference/network/Mink.py:291-354) with BatchNorm(eval)/ReLU/residual
 //                       folded into the convolution epilogues and skip concatenations written in place.
 // Both only sequence the kernels of coords.hip / spconv.hip; no new arithmetic lives here.
+#include <cstdlib>
 #include "pbn_common.h"
 
 using namespace pbn;
@@ -79,7 +80,7 @@ int pbn::coords_build_upper(int n, int want_k5, int x_fastest, void* arena, cons
     for (int l = 0; l < 4; ++l) {
         rc = coords_stride_impl(I(L->coords[l]), counts + l, n, 2 << l, (uint64_t*)(A + L->keys[l + 1]), I(L->vals[l + 1]),
                                 L->capacity[l + 1], I(L->coords[l + 1]), I(L->parent_row[l]), I(L->child_k[l]),
-                                I(L->nbr_down[l]), I(L->up[l]), counts + l + 1, ws, wsb, false, st);
+                                I(L->nbr_down[l]), I(L->up[l]), counts + l + 1, ws, wsb, counts + 8, false, st);
         if (rc != PBN_OK) return rc;
     }
     {   // the k=3 map of every level and the k=5 map of level 0: one launch
@@ -122,17 +123,24 @@ extern "C" size_t pbn_coords_prepare_bytes(int n, int want_k5, pbn_prepare_layou
     P->inv32 = take(N * 4);
     P->sort_keys = take(2 * N * 8);
     P->sort_vals = take(2 * N * 4);
-    P->sort_temp_bytes = (int64_t)sort_pairs_temp_bytes(n);
+    {   // scratch of either pipeline: the library sort's temporary storage / the scan states and level keys of pyramid.hip
+        const size_t a = sort_pairs_temp_bytes(n), b = pyramid_scratch_bytes(n);
+        P->sort_temp_bytes = (int64_t)(a > b ? a : b);
+    }
     P->sort_temp = take((size_t)P->sort_temp_bytes);
     return off;
 }
 
 static int coords_prepare_impl(const int32_t* coords, const int32_t* n_dev, int n, int want_k5, int x_fastest, void* arena,
-                               size_t arena_bytes, const pbn_prepare_layout* P, pbn_stream_t stream) {
+                               size_t arena_bytes, const pbn_prepare_layout* P, pbn_stream_t stream, bool force_hash = false) {
     if (n < 0 || !arena || !P) return PBN_ERR_ARG;
     pbn_prepare_layout chk;
     if (pbn_coords_prepare_bytes(n, want_k5, &chk) > arena_bytes) return PBN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    // PBN_PREPARE_HASH=1: the round-2 pipeline (a hash table per level + the library radix sort), kept as the cross-check of
+    // pyramid.hip (tests/test_pyramid_gpu.py compares every array of the two)
+    static const int hash_env = getenv("PBN_PREPARE_HASH") ? atoi(getenv("PBN_PREPARE_HASH")) : 0;
+    if (!hash_env && !force_hash) return coords_prepare_sorted(coords, n_dev, n, want_k5, x_fastest, arena, P, st);
     char* A = (char*)arena;
     const pbn_coords_layout* L = &P->pyramid;
     auto I = [&](int64_t o) { return (int32_t*)(A + o); };
@@ -169,7 +177,7 @@ static int coords_prepare_impl(const int32_t* coords, const int32_t* n_dev, int 
     if (rc != PBN_OK) return rc;
     // 3. level 0 of the Z-ordered lineage: rows are unique already -> plain insert, value = row
     rc = coords_insert_identity(I(L->coords[0]), n_unique, n, (uint64_t*)(A + L->keys[0]), I(L->vals[0]), L->capacity[0],
-                                I(L->coords[0]), I(L->counts), st);
+                                I(L->coords[0]), I(L->counts), I(L->counts) + 8, st);
     if (rc != PBN_OK) return rc;
     // 4. levels 1..4 and every map
     return coords_build_upper(n, want_k5, x_fastest, arena, L, st);
@@ -185,6 +193,12 @@ extern "C" int pbn_coords_prepare_dev(const int32_t* coords, const int32_t* n_de
                                       void* arena, size_t arena_bytes, const pbn_prepare_layout* P, pbn_stream_t stream) {
     if (!n_dev) return PBN_ERR_ARG;
     return coords_prepare_impl(coords, n_dev, n_cap, want_k5, x_fastest, arena, arena_bytes, P, stream);
+}
+
+// the round-2 pipeline behind the same layout (n_dev may be null): cross-check of pyramid.hip
+extern "C" int pbn_coords_prepare_hash(const int32_t* coords, const int32_t* n_dev, int n_cap, int want_k5, int x_fastest,
+                                       void* arena, size_t arena_bytes, const pbn_prepare_layout* P, pbn_stream_t stream) {
+    return coords_prepare_impl(coords, n_dev, n_cap, want_k5, x_fastest, arena, arena_bytes, P, stream, true);
 }
 
 static inline int esize(int dtype) { return dtype == PBN_F32 ? 4 : 2; }

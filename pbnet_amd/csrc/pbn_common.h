@@ -93,10 +93,10 @@ int coords_unique_impl(const int32_t* coords, const int32_t* n_dev, int n_max, u
 int coords_stride_impl(const int32_t* fine_coords, const int32_t* n_fine_dev, int n_fine_max, int stride_out,
                        uint64_t* table_keys, int32_t* table_vals, int capacity, int32_t* coarse_coords,
                        int32_t* parent_row, int32_t* child_k, int32_t* nbr_down, int32_t* nbr_up, int32_t* n_coarse,
-                       void* workspace, size_t workspace_bytes, bool clear, hipStream_t stream);
+                       void* workspace, size_t workspace_bytes, int32_t* status, bool clear, hipStream_t stream);
 
 int coords_insert_identity(const int32_t* coords, const int32_t* n_dev, int n_max, uint64_t* keys, int32_t* vals,
-                           int capacity, int32_t* out_coords, int32_t* n_out, hipStream_t stream);
+                           int capacity, int32_t* out_coords, int32_t* n_out, int32_t* status, hipStream_t stream);
 int coords_morton_iota(const int32_t* coords, const int32_t* n_dev, int n_max, uint64_t* keys, int32_t* iota,
                        hipStream_t stream);
 int coords_apply_perm(const int32_t* ucoords, const int32_t* perm32, const int32_t* uidx32, const int32_t* inv32, int n_max,
@@ -104,6 +104,12 @@ int coords_apply_perm(const int32_t* ucoords, const int32_t* perm32, const int32
                       hipStream_t stream);
 // executor.hip: the levels above level 0 and every map, given a finished level 0 (coords, table, count)
 int coords_build_upper(int n, int want_k5, int x_fastest, void* arena, const pbn_coords_layout* L, hipStream_t stream);
+int coords_number_first(const int32_t* slot_of_row, const int32_t* table_vals, const int32_t* n_dev, int n_max, int32_t* scan_tmp,
+                        int32_t* newid, int32_t* first_row, int32_t* n_out, const int32_t* status, hipStream_t stream);
+// pyramid.hip: the sorted, hash-free lineage of pbn_coords_prepare (scratch lives in the arena's sort_temp block)
+size_t pyramid_scratch_bytes(int n);
+int coords_prepare_sorted(const int32_t* coords, const int32_t* n_dev, int n, int want_k5, int x_fastest, void* arena,
+                          const pbn_prepare_layout* P, hipStream_t stream);
 // prepare.hip: device radix sort of (key, value) pairs; temp from sort_pairs_temp_bytes(n)
 size_t sort_pairs_temp_bytes(int n);
 int sort_pairs_u64_i32(const uint64_t* keys_in, uint64_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int n,
