@@ -336,7 +336,9 @@ int pbn_local_scene_rows_dev(const int32_t* ent_row_start, const int32_t* ent_me
                              int32_t* coords, void* feat_out, int ld_out, pbn_stream_t stream);
 int pbn_gather_pad_rows_dev(const void* in, int ld_in_bytes, int row_bytes, const int64_t* idx, const int64_t* idx2,
                             int n_cap, const int32_t* n_dev, void* out, int ld_out_bytes, pbn_stream_t stream);
-int pbn_mlp_rows_dev(const void* in, int ld_in, int channels, const int64_t* idx_a, const int64_t* idx_b, int n_cap,
+/* in_rows: the row capacity of `in`; a resolved row index outside [0, in_rows) reads as a row of zeros (an index table of a
+ * level that overflowed its capacity names rows that were never computed). */
+int pbn_mlp_rows_dev(const void* in, int ld_in, int in_rows, int channels, const int64_t* idx_a, const int64_t* idx_b, int n_cap,
                      const int32_t* n_dev, const float* w1, const float* scale, const float* shift, const float* slope,
                      int hidden, const float* w2, const float* b2, int n_out, int sigmoid, void* out, int ld_out, int dtype,
                      pbn_stream_t stream);

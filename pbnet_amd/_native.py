@@ -134,7 +134,7 @@ SIGNATURES = {
                                          c_float, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i32p, c_vp,
                                          c_int, c_vp]),
     "pbn_gather_pad_rows_dev": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i32p, c_vp, c_int, c_vp]),
-    "pbn_mlp_rows_dev": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int,
+    "pbn_mlp_rows_dev": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int,
                                  c_f32p, c_f32p, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "pbn_mask_count_dev": (c_int, [c_vp, c_int, c_float, c_vp, c_int, c_i32p, c_int, c_int, c_i32p, c_i32p, c_vp]),
     "pbn_proposal_rows_dev": (c_int, [c_vp, c_int, c_float, c_vp, c_vp, c_int, c_i32p, c_i32p, c_i32p, c_f32p, c_float,

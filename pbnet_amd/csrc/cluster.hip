@@ -54,12 +54,13 @@ __device__ __forceinline__ unsigned long long pack_key(int seg, int cx, int cy, 
 __device__ __forceinline__ int hash_lookup(const unsigned long long* __restrict__ hkeys, unsigned hmask,
                                            unsigned long long key) {
     unsigned h = hash64(key) & hmask;
-    while (true) {
+    for (unsigned probes = 0; probes <= hmask; ++probes) {     // bounded by the capacity: a full / corrupted table ends the probe
         unsigned long long k = hkeys[h];
         if (k == key) return (int)h;
         if (k == EMPTY_KEY) return -1;
         h = (h + 1) & hmask;
     }
+    return -1;
 }
 
 // ---- segment offsets: exclusive scan of seg_len by one wave; status != 0 when the lengths do not add up -------
@@ -121,11 +122,13 @@ __global__ __launch_bounds__(TPB) void k_cell_insert(const float* __restrict__ o
     const float x = off_xyz[3 * i + 0], y = off_xyz[3 * i + 1], z = off_xyz[3 * i + 2];
     const unsigned long long key = pack_key(seg, cell_coord(x, inv_cell), cell_coord(y, inv_cell), cell_coord(z, inv_cell));
     unsigned h = hash64(key) & hmask;
-    while (true) {
+    bool placed = false;
+    for (unsigned probes = 0; probes <= hmask; ++probes) {     // bounded by the capacity (2x the points: never full unless corrupted)
         unsigned long long prev = atomicCAS(&hkeys[h], EMPTY_KEY, key);
-        if (prev == EMPTY_KEY || prev == key) break;
+        if (prev == EMPTY_KEY || prev == key) { placed = true; break; }
         h = (h + 1) & hmask;
     }
+    if (!placed) { atomicOr(status, 4); h = 0; }               // status != 0: the launch reports invalid input (n_clusters = -1)
     atomicAdd(&hcount[h], 1);
     slot_of_pt[i] = (int)h;
 }

@@ -132,7 +132,7 @@ template <> struct RowIO<__half> {
 template <typename T, int C, int H>
 __global__ __launch_bounds__(TPB) void k_mlp_rows(const T* __restrict__ in, int ld_in, const long long* __restrict__ idx_a,
                                                  const long long* __restrict__ idx_b, int n_cap,
-                                                 const int* __restrict__ n_dev,
+                                                 const int* __restrict__ n_dev, long long in_rows,
                                                  const float* __restrict__ w1, const float* __restrict__ scale,
                                                  const float* __restrict__ shift, const float* __restrict__ slope,
                                                  const float* __restrict__ w2, const float* __restrict__ b2, int n_out,
@@ -142,11 +142,16 @@ __global__ __launch_bounds__(TPB) void k_mlp_rows(const T* __restrict__ in, int 
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     long long row = idx_a ? idx_a[i] : i;
-    if (idx_b) row = idx_b[row];
+    if (idx_b && row >= 0) row = idx_b[row];
     float x[C];
-    const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)row * ld_in);
+    // a resolved row outside the slab (capacity-planned mode: a level overflowed its capacity and the index tables name
+    // rows that were never computed) reads as zeros instead of memory past the slab; the overflow itself is flagged elsewhere
+    const bool inside = row >= 0 && (in_rows < 0 || row < in_rows);
+    const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)(inside ? row : 0) * ld_in);
 #pragma unroll
-    for (int v = 0; v < C / E; ++v) RowIO<T>::unpack(src[v], x + v * E);
+    for (int v = 0; v < C / E; ++v) {
+        RowIO<T>::unpack(inside ? src[v] : make_uint4(0u, 0u, 0u, 0u), x + v * E);
+    }
     float h[H];
 #pragma unroll
     for (int k = 0; k < H; ++k) {
@@ -539,7 +544,7 @@ extern "C" int pbn_gather_pad_rows_dev(const void* in, int ld_in_bytes, int row_
     return gather_pad_rows_impl(in, ld_in_bytes, row_bytes, idx, idx2, n_cap, n_dev, out, ld_out_bytes, stream);
 }
 
-static int mlp_rows_impl(const void* in, int ld_in, int channels, const int64_t* idx_a, const int64_t* idx_b, int n,
+static int mlp_rows_impl(const void* in, int ld_in, long long in_rows, int channels, const int64_t* idx_a, const int64_t* idx_b, int n,
                             const int32_t* n_dev, const float* w1, const float* scale, const float* shift, const float* slope, int hidden,
                             const float* w2, const float* b2, int n_out, int sigmoid, void* out, int ld_out, int dtype,
                             pbn_stream_t stream_) {
@@ -553,7 +558,7 @@ static int mlp_rows_impl(const void* in, int ld_in, int channels, const int64_t*
     const dim3 grid(cdiv(n, TPB));
 #define PBN_MLP(TT, HH)                                                                                                 \
     hipLaunchKernelGGL((k_mlp_rows<TT, 32, HH>), grid, dim3(TPB), 0, stream, (const TT*)in, ld_in,                        \
-                       (const long long*)idx_a, (const long long*)idx_b, n, n_dev, w1, scale, shift, slope, w2, b2,      \
+                       (const long long*)idx_a, (const long long*)idx_b, n, n_dev, in_rows, w1, scale, shift, slope, w2, b2, \
                        n_out,                                                                                            \
                        sigmoid, (TT*)out, ld_out)
     if (dtype == PBN_F32) { if (hidden == 16) PBN_MLP(float, 16); else PBN_MLP(float, 32); }
@@ -569,15 +574,16 @@ extern "C" int pbn_mlp_rows(const void* in, int ld_in, int channels, const int64
                             const float* w1, const float* scale, const float* shift, const float* slope, int hidden,
                             const float* w2, const float* b2, int n_out, int sigmoid, void* out, int ld_out, int dtype,
                             pbn_stream_t stream) {
-    return mlp_rows_impl(in, ld_in, channels, idx_a, idx_b, n, nullptr, w1, scale, shift, slope, hidden, w2, b2, n_out,
+    return mlp_rows_impl(in, ld_in, -1, channels, idx_a, idx_b, n, nullptr, w1, scale, shift, slope, hidden, w2, b2, n_out,
                          sigmoid, out, ld_out, dtype, stream);
 }
 
-extern "C" int pbn_mlp_rows_dev(const void* in, int ld_in, int channels, const int64_t* idx_a, const int64_t* idx_b,
+extern "C" int pbn_mlp_rows_dev(const void* in, int ld_in, int in_rows, int channels, const int64_t* idx_a, const int64_t* idx_b,
                                 int n_cap, const int32_t* n_dev, const float* w1, const float* scale, const float* shift,
                                 const float* slope, int hidden, const float* w2, const float* b2, int n_out, int sigmoid,
                                 void* out, int ld_out, int dtype, pbn_stream_t stream) {
-    return mlp_rows_impl(in, ld_in, channels, idx_a, idx_b, n_cap, n_dev, w1, scale, shift, slope, hidden, w2, b2, n_out,
+    if (in_rows < 0) return PBN_ERR_ARG;
+    return mlp_rows_impl(in, ld_in, in_rows, channels, idx_a, idx_b, n_cap, n_dev, w1, scale, shift, slope, hidden, w2, b2, n_out,
                          sigmoid, out, ld_out, dtype, stream);
 }
 

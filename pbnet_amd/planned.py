@@ -168,7 +168,8 @@ class PlannedForward(object):
         hp = stage_ops._HEADS.setdefault(id(head), stage_ops._HeadParams()).get(head)
         out = torch.empty(int(n_cap), hp.n_out, dtype=feats.dtype, device=feats.device)
         vp = ctypes.c_void_p
-        rc = N.lib().pbn_mlp_rows_dev(vp(feats.data_ptr()), feats.stride(0), hp.channels, N.ptr(idx_a), N.ptr(idx_b), int(n_cap),
+        rc = N.lib().pbn_mlp_rows_dev(vp(feats.data_ptr()), feats.stride(0), int(feats.shape[0]), hp.channels, N.ptr(idx_a),
+                                      N.ptr(idx_b), int(n_cap),
                                       vp(n_dev_ptr), N.ptr(hp.w1), N.ptr(hp.scale), N.ptr(hp.shift), N.ptr(hp.slope), hp.hidden,
                                       N.ptr(hp.w2), N.ptr(hp.b2), hp.n_out, int(hp.sigmoid), vp(out.data_ptr()), hp.n_out,
                                       _DT[feats.dtype], N.current_stream())

@@ -101,6 +101,14 @@ def test_overflow_is_reported_not_written(model):
     small.lv2 = [max(1, v // 2) for v in cap.lv2]
     with pytest.raises(planned.CapacityOverflow):
         planned.PlannedForward(model, small, dtype=torch.float32)(*_args(b), teacher=t)
+    # only level 0 of the score lineage too small: the head behind that U-Net gathers through index tables that name rows
+    # beyond the slab -- pbn_mlp_rows_dev bounds them by the slab's row capacity (zeros, no read past the allocation)
+    for lv in ("lv3", "lv2"):
+        small = planned.Capacities(**{k: getattr(cap, k) for k in cap.FIELDS})
+        setattr(small, lv, [max(1, getattr(cap, lv)[0] // 2)] + list(getattr(cap, lv)[1:]))
+        with pytest.raises(planned.CapacityOverflow):
+            planned.PlannedForward(model, small, dtype=torch.float32)(*_args(b), teacher=t)
+        torch.cuda.synchronize()
     # and the model is intact afterwards
     _same_proposals(planned.PlannedForward(model, cap, dtype=torch.float32)(*_args(b), teacher=t), _eager(model, b, t), 0.0)
 

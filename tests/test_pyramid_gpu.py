@@ -214,3 +214,19 @@ def test_c4_sized_scene():
     batch, _, info = synth.make_val_batch(copies=1, seed=3, room=(6.4, 5.2, 2.7), n_boxes=14, pitch=0.0112, voxel=0.01)
     assert info["n_voxels"] > 1000000
     _compare(batch["xyz_voxel"])
+
+
+def test_probe_of_a_full_table_ends():
+    """Open-addressing probes are bounded by the table capacity (csrc/coords_dev.h): a table without a single empty slot --
+    what a skipped clear or a corrupted arena leaves behind -- answers "not found" instead of spinning for ever."""
+    lib = N.lib()
+    cap = 1024
+    keys = torch.full((cap,), 0x0123456789abcdef, dtype=torch.int64, device=DEV)        # every slot taken by a foreign key
+    vals = torch.zeros(cap, dtype=torch.int32, device=DEV)
+    coords = torch.tensor([[0, 1, 2, 3], [0, 5, 5, 5]], dtype=torch.int32, device=DEV)
+    nbr = torch.full((2, 27), 7, dtype=torch.int32, device=DEV)
+    rc = lib.pbn_kernel_map_cube(N.ptr(coords), None, 2, 3, 1, int(CV.X_FASTEST), N.ptr(keys), N.ptr(vals), cap, N.ptr(nbr),
+                                 N.current_stream())
+    N.check(rc, "pbn_kernel_map_cube")
+    torch.cuda.synchronize()
+    assert bool((nbr == -1).all())
