@@ -86,6 +86,50 @@ def build_scene(copies, dtype, device, workload="c2"):
     return b, t, info, (batch, teacher)
 
 
+def build_batched(seeds, dtype, device):
+    """Several DISTINCT scenes in one forward through the batch index (the reference's own batch axis: PBNet.py:167-170,
+    dataset_preprocess.py:296): scene j of `seeds` becomes batch element j."""
+    from pbnet_amd import synth
+    parts = [synth.make_val_batch(copies=1, **dict(WORKLOADS["c2"], seed=sd)) for sd in seeds]
+    vox, feat, xyz, v2p, off, score = [], [], [], [], [], []
+    nv = 0
+    for j, (bt, tc, _) in enumerate(parts):
+        xv = bt["xyz_voxel"].copy()
+        xv[:, 0] = j
+        vox.append(xv); feat.append(bt["feat_voxel"]); xyz.append(bt["xyz_original"]); v2p.append(bt["v2p_index"] + nv)
+        off.append(tc["offset"]); score.append(tc["sem_score"])
+        nv += len(xv)
+    b = {"xyz_voxel": torch.from_numpy(np.concatenate(vox)).to(device),
+         "feat_voxel": torch.from_numpy(np.concatenate(feat)).to(device).to(dtype),
+         "xyz_original": torch.from_numpy(np.concatenate(xyz)).to(device),
+         "v2p_index": torch.from_numpy(np.concatenate(v2p)).to(device)}
+    t = {"sem_score": torch.from_numpy(np.concatenate(score)).to(device), "offset": torch.from_numpy(np.concatenate(off)).to(device)}
+    info = {"n_points": int(sum(p[2]["n_points"] for p in parts)), "n_voxels": int(nv), "scenes": len(seeds)}
+    return b, t, info
+
+
+def timed_leg(model, b, t, inflight, device, steps, warmup=None, blocks=3):
+    """scenes-forwards per second of a side configuration (median of `blocks` timed blocks) + one forward alone, in ms."""
+    r = Runner(model, b, t, inflight, device)
+    r.run(inflight)
+    r.run(max(2, steps // 4) if warmup is None else warmup)
+    bl = []
+    for _ in range(blocks):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r.run(steps)
+        torch.cuda.synchronize()
+        bl.append(time.perf_counter() - t0)
+    e = float(np.median(bl))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        one_step(model, b, t)
+    torch.cuda.synchronize()
+    alone = (time.perf_counter() - t1) / 5 * 1e3
+    return steps / e, e / steps * 1e3, alone, r.result()
+
+
 def build_workload(rank, copies, dtype, device, workload="c2"):
     cfg, model = build_model(device)
     b, t, info, raw = build_scene(copies, dtype, device, workload)
@@ -382,6 +426,7 @@ def main():
     n_prop = int(ret["proposals"][1].shape[0] - 1)
 
     roof = cpu = single_ms = stages = grouping = tta = None
+    legs = {}
     if rank == 0:
         n_probe = max(2, min(args.steps, 5)) * args.inflight
 
@@ -484,6 +529,47 @@ def main():
                        "proposals_per_step": int(r3.result()["proposals"][1].shape[0] - 1)}
                 del b3, t3, r3
                 phase("tta3_leg")
+            if args.copies == 1 and world == 1 and args.workload == "c2":
+                # the other configurations of BASELINE.json on the same line (each a short run; the headline stays configs[1]):
+                # fp32 = the parity configuration (1e-4 against the oracle is asserted in fp32: tests/test_bench_workload_gpu.py)
+                k = max(args.inflight, args.steps // 3)
+                b32 = dict(b, feat_voxel=b["feat_voxel"].float())
+                v, ms, alone, _ = timed_leg(model, b32, t, args.inflight, device, k)
+                legs["fp32"] = {"value": round(v, 3), "unit": "scenes/s", "ms_per_step": round(ms, 3),
+                                "one_scene_in_flight_ms_per_scene": round(alone, 3), "dtype": "f32",
+                                "note": "configs[1] with fp32 feature slabs (v_mfma_f32_16x16x4_f32): the configuration the "
+                                        "1e-4 parity tests run in"}
+                del b32
+                # three DISTINCT scenes per forward through the batch index: every launch of the coarse levels gets 3x the rows
+                bb, tb, ib = build_batched((2, 4, 5), dtype, device)
+                v, ms, alone, rb = timed_leg(model, bb, tb, args.inflight, device, max(args.inflight, k // 2))
+                legs["batched3"] = {"value": round(3 * v, 3), "unit": "scenes/s (3 distinct scenes per forward)",
+                                    "forwards_per_s": round(v, 3), "ms_per_forward": round(ms, 3),
+                                    "one_forward_in_flight_ms": round(alone, 3), "points_per_forward": ib["n_points"],
+                                    "voxels_per_forward": ib["n_voxels"],
+                                    "proposals_per_forward": int(rb["proposals"][1].shape[0] - 1)}
+                del bb, tb, rb
+                # configs[3]: the dense 1 cm scene (rulebook build + gather/scatter stress)
+                b4, t4, i4, _ = build_scene(1, dtype, device, "c4")
+                v, ms, alone, r4 = timed_leg(model, b4, t4, args.inflight, device, max(args.inflight, k // 4), warmup=args.inflight)
+                legs["c4"] = {"value": round(v, 3), "unit": "scenes/s", "ms_per_step": round(ms, 3),
+                              "one_scene_in_flight_ms_per_scene": round(alone, 3), "points_per_step": i4["n_points"],
+                              "voxels_per_step": i4["n_voxels"], "proposals_per_step": int(r4["proposals"][1].shape[0] - 1),
+                              "workload": "configs[3]: %d pts, %d voxels @1cm" % (i4["n_points"], i4["n_voxels"])}
+                del b4, t4, r4
+                torch.cuda.empty_cache()
+                phase("config_legs")
+                # configs[2] on this one rank: model_fn forward + losses + backward + gradient reduction + Adam
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                import train_step as TS
+                ph = {}
+                e, comm, loss, it = TS.run_training(world, rank, device, dist, steps=6, warmup=2, phases_out=ph)
+                legs["train_step"] = {"value": round(6 / e, 3), "unit": "scenes/s per rank (configs[2]: bf16 training step, "
+                                      "one scene per rank)", "ms_per_step": round(e / 6 * 1e3, 2),
+                                      "allreduce_tail_ms_per_step": round(comm * 1e3, 2), "loss": round(loss, 5),
+                                      "points_per_scene": it["n_points"], "voxels_per_scene": it["n_voxels"],
+                                      "phases_ms_synchronised": {k_: round(v_, 2) for k_, v_ in ph.items()}}
+                phase("train_step_leg")
             if world == 1 and not args.no_cpu_baseline:
                 cpu = cpu_baseline(cfg, model, raw)
                 phase("cpu_baseline")
@@ -528,6 +614,7 @@ def main():
             line["grouping"] = grouping
         if tta is not None:
             line["tta3"] = tta
+        line.update(legs)
         if cpu is not None:
             line["cpu_baseline"] = cpu
         line["phases_s"] = phases

@@ -19,33 +19,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--comm-dtype", default="f32", choices=["bf16", "f32"], help="gradient dtype on the wire")
-    ap.add_argument("--no-overlap", action="store_true", help="all-reduce after backward instead of from gradient hooks")
-    ap.add_argument("--phases", action="store_true", help="also run 5 steps with a synchronisation after every phase and print the split")
-    ap.add_argument("--small", action="store_true", help="a 20 k-point room instead of a ScanNet-sized scene (smoke runs)")
-    args = ap.parse_args()
-    import torch.distributed as dist
+def run_training(world, rank, dev, dist, steps=5, warmup=2, dtype=None, comm_dtype=None, overlap=True, phases_out=None,
+                 small=False):
+    """configs[2] on this rank's share (one scene), `dist` = an initialised torch.distributed (or None at world 1 without a
+    process group: the reducer then has nothing to exchange).  Returns (seconds for `steps` steps on this rank, mean
+    all-reduce tail, last loss, scene info).  Importable: bench.py's `train_step` leg calls it."""
     from pbnet_amd import dist as pd, synth
     from pbnet_amd.config import get_config
     from pbnet_amd.network.PBNet import PBNet, model_fn
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29517")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
+    dtype = dtype or torch.bfloat16
+    comm_dtype = comm_dtype or torch.float32
     cfg = get_config(batch_size=1, cluster_epoch=0)
     torch.manual_seed(22)                                           # same initial weights on every rank
     model = PBNet(cfg).to(dev).train()
-    kw = dict(room=(1.6, 1.3, 1.2), n_boxes=4, pitch=0.03, classes=(17, 10)) if args.small else {}
+    kw = dict(room=(1.6, 1.3, 1.2), n_boxes=4, pitch=0.03, classes=(17, 10)) if small else {}
     batch_np, teacher_np, info = synth.make_train_batch(seed=10 + rank, copies=1, **kw)
     t = torch.from_numpy
     batch = {k: t(v).to(dev) for k, v in batch_np.items()}
@@ -54,35 +41,33 @@ def main():
     fwd = model.forward
     model.forward = lambda *a, **k: fwd(*a, teacher=teacher, **k)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)   # train.py:331 optim.Adam; one multi-tensor launch per step
-    reducer = pd.GradientReducer(model.parameters(), comm_dtype={"bf16": torch.bfloat16, "f32": torch.float32}[args.comm_dtype],
-                                 overlap=not args.no_overlap)
+    reducer = pd.GradientReducer(model.parameters(), comm_dtype=comm_dtype, overlap=overlap)
     t_comm = [0.0]
-
     phases = {}
 
     def mark(name, t_prev, sync):
         if sync:
             torch.cuda.synchronize()
-        t = time.perf_counter()
-        phases[name] = phases.get(name, 0.0) + (t - t_prev)
-        return t
+        tt = time.perf_counter()
+        phases[name] = phases.get(name, 0.0) + (tt - t_prev)
+        return tt
 
     def step_phases():
-        """The same step with a device synchronisation after every phase (--phases): where the host waits for the GPU
-        and where the GPU waits for the host.  Not the timed configuration."""
-        t = time.perf_counter()
+        """The same step with a device synchronisation after every phase: where the host waits for the GPU and where the
+        GPU waits for the host.  Not the timed configuration."""
+        tt = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         loss, pred, visual, meter = model_fn(batch, model, 1, cfg, "train")
-        t = mark("forward_host", t, False)
-        t = mark("forward_gpu_tail", t, True)
+        tt = mark("forward_host", tt, False)
+        tt = mark("forward_gpu_tail", tt, True)
         loss.backward()
-        t = mark("backward_host", t, False)
-        t = mark("backward_gpu_tail", t, True)
+        tt = mark("backward_host", tt, False)
+        tt = mark("backward_gpu_tail", tt, True)
         reducer.finish()
-        t = mark("allreduce", t, True)
+        tt = mark("allreduce", tt, True)
         opt.step()
-        t = mark("optimizer_host", t, False)
-        t = mark("optimizer_gpu_tail", t, True)
+        tt = mark("optimizer_host", tt, False)
+        tt = mark("optimizer_gpu_tail", tt, True)
         return loss
 
     def step():
@@ -96,24 +81,63 @@ def main():
         t_comm[0] += time.perf_counter() - c0
         opt.step()
         return loss
-    for _ in range(args.warmup):
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None and dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
         step()
     t_comm[0] = 0.0
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    if args.phases:
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if phases_out is not None:
         for _ in range(5):
             step_phases()
-        if rank == 0:
-            print("phases ms/step (synchronised after each): " + ", ".join("%s %.2f" % (k, v / 5 * 1e3) for k, v in phases.items()),
-                  file=sys.stderr)
+        phases_out.update({k: v / 5 * 1e3 for k, v in phases.items()})
+    if dist is not None and dist.is_initialized():
+        pd.sync_buffers(model)                                      # what precedes validation / checkpoint_save
+    return elapsed, t_comm[0] / max(steps, 1), float(loss), info
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--comm-dtype", default="f32", choices=["bf16", "f32"], help="gradient dtype on the wire")
+    ap.add_argument("--no-overlap", action="store_true", help="all-reduce after backward instead of from gradient hooks")
+    ap.add_argument("--phases", action="store_true", help="also run 5 steps with a synchronisation after every phase and print the split")
+    ap.add_argument("--small", action="store_true", help="a 20 k-point room instead of a ScanNet-sized scene (smoke runs)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rendezvous / collectives dry run (tests)")
+    args = ap.parse_args()
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dtypes = {"bf16": torch.bfloat16, "f32": torch.float32}
+    phases = {} if args.phases else None
+    e, comm, loss, info = run_training(world, rank, dev, dist, args.steps, args.warmup, dtypes[args.dtype], dtypes[args.comm_dtype],
+                                       not args.no_overlap, phases, args.small)
+    el = torch.tensor([e], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    if phases and rank == 0:
+        print("phases ms/step (synchronised after each): " + ", ".join("%s %.2f" % kv for kv in phases.items()), file=sys.stderr)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    pd.sync_buffers(model)                                          # what precedes validation / checkpoint_save
-    lossv = torch.tensor([float(loss)], device=dev)
+    lossv = torch.tensor([loss], device=el.device)
     dist.all_reduce(lossv)
     dist.barrier()
     dist.destroy_process_group()
@@ -125,7 +149,7 @@ def main():
         print(json.dumps({"metric": "training scenes/s (configs[2]: bf16 step, one scene per rank, RCCL gradient all-reduce)",
                           "value": round(world * args.steps / e, 3), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
                           "ms_per_step": round(e / args.steps * 1e3, 2), "dtype": args.dtype, "comm_dtype": args.comm_dtype,
-                          "allreduce_tail_ms_per_step": round(t_comm[0] / args.steps * 1e3, 2), "overlap": not args.no_overlap,
+                          "allreduce_tail_ms_per_step": round(comm * 1e3, 2), "overlap": not args.no_overlap,
                           "mean_loss_last_step": round(float(lossv) / world, 5),
                           "points_per_scene": info["n_points"], "voxels_per_scene": info["n_voxels"]}), flush=True)
 
