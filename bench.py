@@ -356,6 +356,52 @@ def init_process_group(world, rank, device):
         return None, "FAILED at world 1: %s: %s" % (type(e).__name__, str(e)[:200])
 
 
+def dry_run(args):
+    """The launch contract without a GPU: WORLD_SIZE / RANK / LOCAL_RANK / MASTER_* from the environment, one process per
+    rank, warmup + EXACTLY K steps between barriers, MAX over ranks, ONE JSON line from rank 0.  The step is a stand-in (a
+    per-rank seeded numpy reduction); every field that describes the device path is marked as not measured."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pbnet_amd.dist import shard_scenes
+    mine = shard_scenes(8 * world, rank, world)                         # the scene shard this rank would take (eval_map.py:48-50)
+    rng = np.random.default_rng(1000 + rank)
+    work = rng.standard_normal(200000)
+
+    def step():
+        return float(np.sort(work)[::97].sum())
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    shard_sizes = torch.zeros(world, dtype=torch.int64)
+    shard_sizes[rank] = len(mine)
+    dist.all_reduce(shard_sizes)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        e = float(el.item())
+        print(json.dumps({"metric": "scenes/sec fwd+cluster (ScanNet ~150k pts/scene)", "value": round(world * args.steps / e, 3),
+                          "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(e / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": args.dtype, "data": "none (dry run)", "dry_run": True,
+                          "config": {"workload": "stand-in step on the host: launch plumbing only, NOT a measurement",
+                                     "local_rank_of_rank0": local_rank, "scene_shard_sizes": shard_sizes.tolist(),
+                                     "rccl": "not used (gloo)"},
+                          "roofline": None}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -370,7 +416,12 @@ def main():
                     help="scenes in flight per GPU (one host thread + HIP stream each); 1 = the reference's loop")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
                     help="c2 = BASELINE configs[1] (default, the metric); c4 = configs[3], the dense 1 cm stress scene")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: rendezvous over gloo, a stand-in step, the same barriers / MAX-over-ranks timing / JSON line "
+                         "(tests/test_launch_cpu.py proves the N-rank plumbing before an 8-GPU node runs it)")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
     phases = {}
     t_phase = [time.perf_counter()]
 

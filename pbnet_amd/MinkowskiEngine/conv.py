@@ -311,6 +311,8 @@ def wgrad_native(feats, grad_out, nbr, cin, cout):
     assert feats.dtype == grad_out.dtype and feats.stride(1) == 1 and grad_out.stride(1) == 1
     dev = feats.device
     lib = N.lib()
+    if int(feats.shape[0]) == 0 or int(grad_out.shape[0]) == 0:     # an empty level: no pairs, the gradient is zero
+        return torch.zeros(1 if nbr is None else int(nbr.shape[1]), cin, cout, dtype=torch.float32, device=dev)
     if nbr is None:
         k, in_idx, out_idx, seg_begin, n_pairs = 1, None, None, None, int(feats.shape[0])
     else:

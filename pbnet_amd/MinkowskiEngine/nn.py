@@ -125,6 +125,15 @@ def bn_act(norm, x, residual=None, relu=True):
     return out.replace_feature(torch.relu(out.F)) if relu else out
 
 
+def _flush_ticks_hook(module, prefix, keep_vars):
+    module.flush_ticks()
+
+
+def _drop_ticks_hook(module, state_dict, prefix, *unused):
+    if prefix + "num_batches_tracked" in state_dict:
+        module.__dict__["_pending_ticks"] = 0
+
+
 class _TickedBatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d whose num_batches_tracked increments are counted on the host and applied when somebody looks at the
     buffer (attribute access, state_dict): one tiny launch per layer and step less on the native training path."""
@@ -132,7 +141,8 @@ class _TickedBatchNorm1d(nn.BatchNorm1d):
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self.__dict__["_pending_ticks"] = 0
-        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_ticks())
+        self.register_state_dict_pre_hook(_flush_ticks_hook)            # a module-level function: the module stays picklable
+        self.register_load_state_dict_pre_hook(_drop_ticks_hook)        # a loaded counter replaces the pending increments
 
     def flush_ticks(self):
         t = self.__dict__.get("_pending_ticks", 0)
@@ -146,6 +156,18 @@ class _TickedBatchNorm1d(nn.BatchNorm1d):
         if name == "num_batches_tracked":
             self.flush_ticks()
         return super().__getattr__(name)
+
+    def _apply(self, fn, *a, **k):            # .to() / .half() / .cuda() walk _buffers directly
+        self.flush_ticks()
+        return super()._apply(fn, *a, **k)
+
+    def buffers(self, *a, **k):
+        self.flush_ticks()
+        return super().buffers(*a, **k)
+
+    def named_buffers(self, *a, **k):
+        self.flush_ticks()
+        return super().named_buffers(*a, **k)
 
 
 class MinkowskiBatchNorm(nn.Module):

@@ -106,8 +106,11 @@ class GradientReducer(object):
     def _on_grad(self, p):
         bi, pi = self._bucket_of[id(p)]
         b = self.buckets[bi]
-        if b["filled"][pi]:                      # a second backward before finish(): the hook sees the accumulated grad
-            return
+        if b["filled"][pi]:
+            # a second backward before finish(): the bucket holds (and may already have sent) the FIRST gradient only, the
+            # accumulated one would be lost -- refuse instead of averaging the wrong thing
+            raise RuntimeError("GradientReducer: backward ran twice before finish(); with gradient accumulation build the "
+                               "reducer with overlap=False (the all-reduce then starts in finish())")
         flat = self._flat(b, p)
         flat[b["offsets"][pi]:b["offsets"][pi] + p.numel()].copy_(p.grad.detach().reshape(-1))
         b["filled"][pi] = True
@@ -172,6 +175,9 @@ def sync_buffers(module, src=0):
     rank `src`'s buffers, in one flat broadcast per dtype."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
+    for m in module.modules():               # lazily counted num_batches_tracked (MinkowskiEngine/nn.py) -> into the buffers
+        if hasattr(m, "flush_ticks"):
+            m.flush_ticks()
     groups = {}
     for b in module.buffers():
         groups.setdefault((b.dtype, b.device), []).append(b)

@@ -106,6 +106,51 @@ def run_training(world, rank, dev, dist, steps=5, warmup=2, dtype=None, comm_dty
     return elapsed, t_comm[0] / max(steps, 1), float(loss), info
 
 
+def dry_run(args):
+    """The N-rank training entry without a GPU: per-rank seeded data, gradient all-reduce through pbnet_amd.dist
+    .GradientReducer (hooks during backward, buckets in reverse registration order, a parameter unused on every rank keeps
+    grad None), optimizer step, replicas stay bit-identical."""
+    import torch.distributed as dist
+    from pbnet_amd import dist as pd
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(22)                                           # same initial weights on every rank
+    model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+    unused = torch.nn.Linear(4, 4)                                  # a branch no rank trains (cluster branch before cluster_epoch)
+    params = list(model.parameters()) + list(unused.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3)
+    reducer = pd.GradientReducer(params, comm_dtype=torch.float32, overlap=not args.no_overlap)
+    g = torch.Generator().manual_seed(10 + rank)                    # every rank its own scene
+    x, y = torch.randn(64, 16, generator=g), torch.randn(64, 4, generator=g)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        opt.zero_grad(set_to_none=True)
+        loss = ((model(x) - y) ** 2).mean()
+        loss.backward()
+        reducer.finish()
+        opt.step()
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    lo, hi = flat.clone(), flat.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    lossv = torch.tensor([float(loss)])
+    dist.all_reduce(lossv)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "training scenes/s (dry run: stand-in model, launch plumbing only)", "dry_run": True,
+                          "n_gpus": world, "steps": args.steps, "value": round(world * args.steps / float(el), 3),
+                          "replicas_identical": bool(torch.equal(lo, hi)), "unused_grads_none": all(p.grad is None for p in unused.parameters()),
+                          "mean_loss_last_step": round(float(lossv) / world, 6)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
@@ -116,7 +161,12 @@ def main():
     ap.add_argument("--phases", action="store_true", help="also run 5 steps with a synchronisation after every phase and print the split")
     ap.add_argument("--small", action="store_true", help="a 20 k-point room instead of a ScanNet-sized scene (smoke runs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rendezvous / collectives dry run (tests)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: gloo, a small dense stand-in model, the SAME GradientReducer / barriers / MAX-over-ranks / "
+                         "JSON line (tests/test_launch_cpu.py)")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

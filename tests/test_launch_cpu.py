@@ -1,0 +1,54 @@
+"""CPU tier: the N-rank ENTRY POINTS themselves under the driver's launcher (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node 2 --master-addr 127.0.0.1 --master-port P <entry> --gpus 2 ...`), with gloo standing in for RCCL and a stand-in
+step for the device work (`--dry-run`): argument parsing, environment rendezvous, barriers, MAX-over-ranks timing, scene
+sharding and the ONE JSON line of rank 0 are exercised before an 8-GPU node ever runs them.  No scaling curve has been
+measured on hardware: this pins the plumbing only (/root/reference/train.py:323-345, eval_map.py:48-50)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(entry, extra, nproc=2):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, entry)] + extra
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout            # ONE JSON line, printed by rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_entry_two_ranks():
+    line = _launch("bench.py", ["--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run"])
+    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1
+    assert line["scaling"] == "weak" and line["higher_is_better"] is True and line["unit"] == "scenes/s"
+    assert abs(line["value"] - 2 * 4 / (line["ms_per_step"] * 4e-3)) / line["value"] < 1e-3     # whole-job aggregate over both ranks
+    assert line["config"]["scene_shard_sizes"] == [8, 8]                                       # 16 scenes, round-robin
+    assert line["roofline"] is None
+
+
+def test_bench_entry_refuses_a_mismatched_world():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert out.returncode != 0
+
+
+def test_train_step_entry_two_ranks():
+    line = _launch("scripts/train_step.py", ["--steps", "3", "--warmup", "1", "--dry-run"])
+    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["steps"] == 3
+    assert line["replicas_identical"] is True            # the same averaged gradient reached both replicas every step
+    assert line["unused_grads_none"] is True             # find_unused_parameters semantics: no state for untrained branches
