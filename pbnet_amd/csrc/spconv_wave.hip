@@ -90,8 +90,11 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, f32x4 v, int o
 }
 
 // channel tiles per LDS reduction round of a K-split workgroup: all of them when the KW partial tiles fit in 64 KiB
+#ifndef PBN_WAVE_RED_KB
+#define PBN_WAVE_RED_KB 64
+#endif
 constexpr int ksplit_round_tiles(int kw, int tm, int nt) {
-    return (kw * tm * nt * 64 <= 64 * 1024) ? nt : (nt < 2 ? nt : 2);
+    return (kw * tm * nt * 64 <= PBN_WAVE_RED_KB * 1024) ? nt : (nt < 2 ? nt : 2);
 }
 
 // blockIdx -> (row tile, channel-tile group).  Row-major launches keep contiguous row-tile ranges per XCD (neighbouring
@@ -571,7 +574,7 @@ int launch_wave(const ConvArgs& a, int dtype, int force_cfg, hipStream_t stream)
 bool wave_family_wanted(const ConvArgs& a, int dtype) {
     (void)dtype;
     static const int fam = getenv("PBN_CONV_FAMILY") ? atoi(getenv("PBN_CONV_FAMILY")) : 2;
-    static const int max_rows = getenv("PBN_WAVE_MAX_ROWS") ? atoi(getenv("PBN_WAVE_MAX_ROWS")) : 20000;
+    static const int max_rows = getenv("PBN_WAVE_MAX_ROWS") ? atoi(getenv("PBN_WAVE_MAX_ROWS")) : 30000;   // 30 k instead of 20 k: level with the tile family on 26 k-row levels and no split-K reduce launch left in a forward
     static const double max_macs = getenv("PBN_WAVE_MAX_GMACS") ? atof(getenv("PBN_WAVE_MAX_GMACS")) * 1e9 : 1.0e10;
     if (a.K > 128) return false;
     if (fam == 0) return false;
