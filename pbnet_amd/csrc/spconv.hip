@@ -35,11 +35,10 @@ constexpr int CONV_TPB = 256;
 
 constexpr int CGMAX = 4;  // channel chunks (steps) per group
 
-// Row gathers in the quad-coalesced lane order of spconv_wave.hip (lane 4 r + c fetches chunk c of row r; the operand order
-// is restored by ds_bpermute before the MFMAs): experiment switch, see the header of spconv_wave.hip.
-#ifndef PBN_TILE_XCOAL
-#define PBN_TILE_XCOAL 0
-#endif
+// (Round 3: the quad-coalesced row gathers of spconv_wave.hip -- lane 4 r + c fetches chunk c of row r, operand order
+// restored by ds_bpermute -- were tried here too and LOSE: L0 96->96 82 -> 105 us with the permutes in front of the MFMAs,
+// 113 us with them one chunk ahead.  This kernel's LDS pipe already carries the weight DMA and the fragment reads; the
+// crossbar traffic of 24 permutes per group and wave does not fit beside them.)
 
 #define PBN_LDS_ADDR(p) ((unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)(p)))
 
@@ -190,9 +189,6 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
         for (int t = 0; t < NT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int g = lane >> 4, rl = lane & 15;
-    const int xrow = PBN_TILE_XCOAL ? (lane >> 2) : rl;          // the row of a fragment this lane gathers, its chunk of a step
-    const int xchunk = PBN_TILE_XCOAL ? (lane & 3) : g;
-    const int xpose_addr = (4 * (lane & 15) + (lane >> 4)) * 4;  // operand-order lane 16 g + r pulls from lane 4 r + g
 
     // Both operands come in through buffer resources: a gather is ONE instruction with a 32-bit per-lane byte offset,
     // and a fragment without a neighbour simply uses an out-of-range offset -- the hardware bounds check returns
@@ -217,10 +213,10 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
         int ko_, cv_;                                                                                                 \
         if (wide) {                                                                                                   \
             const int pk_ = __builtin_amdgcn_readfirstlane(s_gko[POS]);                                               \
-            ko_ = pk_ & 0xffff; cv_ = (pk_ >> 16) * (CG) * 4 + xchunk;                                                \
-        } else { const int v_ = (GI) * 4 + xchunk; ko_ = v_ >> vshift; cv_ = v_ & (vpo - 1); }                        \
+            ko_ = pk_ & 0xffff; cv_ = (pk_ >> 16) * (CG) * 4 + g;                                                     \
+        } else { const int v_ = (GI) * 4 + g; ko_ = v_ >> vshift; cv_ = v_ & (vpo - 1); }                             \
         _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                              \
-            const int r_ = wave * RW + f * 16 + xrow;                                                                 \
+            const int r_ = wave * RW + f * 16 + rl;                                                                   \
             const int src_ = ((MORE) && ko_ < K) ? s_nbr[r_ * KS + ko_] : -1;                                         \
             VOFF[f] = (src_ >= 0 && !(a.dbg & 4)) ? (unsigned)src_ * ld_bytes + (unsigned)cv_ * 16u : OOB;            \
         }                                                                                                             \
@@ -298,15 +294,8 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
             if (c == (CG) - 1) { PBN_STAMP(POS, 5); }                                                                 \
             if (active_) {                                                                                            \
                 if (c + 1 < (CG)) PBN_LOAD_WF(wf_[(c + 1) & 1], cur_, c + 1);                                         \
-                u32x4 xo_[NF];                                                                                        \
-                _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                      \
-                    if (PBN_TILE_XCOAL) {                                                                             \
-                        _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                 \
-                            xo_[f][d] = (unsigned)__builtin_amdgcn_ds_bpermute(xpose_addr, (int)x[c][f][d]);          \
-                    } else xo_[f] = x[c][f];                                                                          \
-                }                                                                                                     \
                 _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
-                    _Pragma("unroll") for (int f = 0; f < NF; ++f) mfma_step<T>(wf_[c & 1][t], xo_[f], acc[f][t]);    \
+                    _Pragma("unroll") for (int f = 0; f < NF; ++f) mfma_step<T>(wf_[c & 1][t], x[c][f], acc[f][t]);   \
                 }                                                                                                     \
             }                                                                                                         \
             PBN_LOAD_X(vnext_, c);                                                                                    \
