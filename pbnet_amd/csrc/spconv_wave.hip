@@ -96,6 +96,9 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, f32x4 v, int o
 constexpr int ksplit_round_tiles(int kw, int tm, int nt) {
     return (kw * tm * nt * 64 <= PBN_WAVE_RED_KB * 1024) ? nt : (nt < 2 ? nt : 2);
 }
+// row pitch of the reduction buffer in floats: + 4, so that the 16 rows a ds_write_b128 lane group stores in one LDS cycle
+// start 36 dwords apart = in 16 different 4-bank groups (at the natural pitch of 32 dwords they alternate between two)
+constexpr int ksplit_red_pitch(int ntb) { return ntb * 16 + 4; }
 
 // blockIdx -> (row tile, channel-tile group).  Row-major launches keep contiguous row-tile ranges per XCD (neighbouring
 // tiles gather overlapping rows); WEIGHT-major launches (a.wmajor: the packed weights outweigh the input slab, i.e. the
@@ -408,6 +411,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     } else {
         // fixed-order sum of the KW partial tiles through LDS, NTB channel tiles per round, then the epilogue
         constexpr int RP = NTB * 16;   // floats per row per round
+        constexpr int RPP = ksplit_red_pitch(NTB);   // ... and the buffer's row pitch
         T* out = reinterpret_cast<T*>(a.out);
         const T* res = reinterpret_cast<const T*>(a.residual);
 #pragma unroll
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
 #pragma unroll
                 for (int tt = 0; tt < NTB; ++tt) {
                     const f32x4 v = acc[f][t0 + tt];
-                    *reinterpret_cast<float4*>(s_red + ((size_t)(wave * TM + f * 16 + rl) * RP + tt * 16 + g * 4)) =
+                    *reinterpret_cast<float4*>(s_red + ((size_t)(wave * TM + f * 16 + rl) * RPP + tt * 16 + g * 4)) =
                         make_float4(v[0], v[1], v[2], v[3]);
                 }
             __syncthreads();
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
                 f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int w = 0; w < KW; ++w) {
-                    const float4 s = *reinterpret_cast<const float4*>(s_red + ((size_t)(w * TM + r) * RP + q * 4));
+                    const float4 s = *reinterpret_cast<const float4*>(s_red + ((size_t)(w * TM + r) * RPP + q * 4));
                     v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
                 }
                 if (a.scale) {
@@ -464,7 +468,7 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
     if (a.ntiles_total % NT) return PBN_ERR_UNSUPPORTED;
     const int KS = a.K | 1;
     size_t lds = sizeof(int) * (size_t)((TM * KS + 3) & ~3);
-    if (KSPLIT) lds += 16 + sizeof(float) * ((size_t)2 * NT * 16 + (size_t)KW * TM * NTB * 16);
+    if (KSPLIT) lds += 16 + sizeof(float) * ((size_t)2 * NT * 16 + (size_t)KW * TM * ksplit_red_pitch(NTB));
     else lds += 16 + sizeof(unsigned) * (size_t)((KW * (a.n_steps + 2 * MAX_DEPTH) + 3) & ~3);
     if (lds > 160 * 1024 || a.K > 128 || a.n_steps > 0xfffe) return PBN_ERR_UNSUPPORTED;
     auto kern = k_spconv_wave<T, NF, NT, KW, KSPLIT>;
