@@ -608,7 +608,6 @@ __global__ __launch_bounds__(TPB) void k_maps_down(const DownJob jb) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_par = real_n(jb.n_parents_dev, jb.n_max);
     int* tab = s_tab[wave];
-    const int per_row = 27 + (jb.k5 ? 125 : 0);
     for (int par = blockIdx.x * (TPB / 64) + wave; par < n_par; par += gridDim.x * (TPB / 64)) {
         const int q = lane < 27 ? jb.k3_up[(size_t)par * 27 + lane] : -1;
 #pragma unroll
@@ -619,21 +618,33 @@ __global__ __launch_bounds__(TPB) void k_maps_down(const DownJob jb) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // the children are consecutive rows (Z-order), so their maps are ONE contiguous block of each output: the lanes
+        // stride over (child, offset) entries; child j of the block has parity cks[j]
+        int first = -1, nchild = 0;
+        unsigned cks = 0;                                               // 3 bits per present child, in row order
+#pragma unroll
         for (int ck = 0; ck < 8; ++ck) {
             const int row = tab[13 * 8 + ck];                           // the parent is its own neighbour 13
-            if (row < 0) continue;
-            for (int e = lane; e < per_row; e += 64) {
-                const bool five = e >= 27;
-                const int k = five ? e - 27 : e;
-                int dx, dy, dz;
-                cube_offset(k, five ? 5 : 3, jb.x_fastest, dx, dy, dz);
-                const int tx = (ck & 1) + dx, ty = ((ck >> 1) & 1) + dy, tz = ((ck >> 2) & 1) + dz;
-                const int px = tx >> 1, py = ty >> 1, pz = tz >> 1;      // parent's neighbour, each in -1..1
-                const int kp3 = jb.x_fastest ? (px + 1) + 3 * (py + 1) + 9 * (pz + 1) : (pz + 1) + 3 * (py + 1) + 9 * (px + 1);
-                const int res = tab[kp3 * 8 + ((tx & 1) + 2 * (ty & 1) + 4 * (tz & 1))];
-                if (five) jb.k5[(size_t)row * 125 + k] = res; else jb.k3[(size_t)row * 27 + k] = res;
-            }
+            if (row >= 0) { if (first < 0) first = row; cks |= (unsigned)ck << (3 * nchild); ++nchild; }
         }
+        auto entry = [&](int j, int k, int ksize) -> int {
+            const int ck = (int)(cks >> (3 * j)) & 7;
+            int dx, dy, dz;
+            cube_offset(k, ksize, jb.x_fastest, dx, dy, dz);
+            const int tx = (ck & 1) + dx, ty = ((ck >> 1) & 1) + dy, tz = ((ck >> 2) & 1) + dz;
+            const int px = tx >> 1, py = ty >> 1, pz = tz >> 1;          // parent's neighbour, each in -1..1
+            const int kp3 = jb.x_fastest ? (px + 1) + 3 * (py + 1) + 9 * (pz + 1) : (pz + 1) + 3 * (py + 1) + 9 * (px + 1);
+            return tab[kp3 * 8 + ((tx & 1) + 2 * (ty & 1) + 4 * (tz & 1))];
+        };
+        for (int e = lane; e < nchild * 27; e += 64) {
+            const int j = e / 27;
+            jb.k3[(size_t)first * 27 + e] = entry(j, e - j * 27, 3);
+        }
+        if (jb.k5)
+            for (int e = lane; e < nchild * 125; e += 64) {
+                const int j = e / 125;
+                jb.k5[(size_t)first * 125 + e] = entry(j, e - j * 125, 5);
+            }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -700,7 +711,8 @@ int coords_prepare_sorted(const int32_t* coords, const int32_t* n_dev, int n, in
     if (!cv.ok) return PBN_ERR_WORKSPACE;
     const int cap = pbn_hash_capacity(n);
     const int gb = (int)(cdiv(n, TPB * 4) < 2048 ? cdiv(n, TPB * 4) : 2048);
-    hipLaunchKernelGGL(k_insert_bbox, dim3(gb), dim3(TPB), 0, st, coords, n_dev, n, (u64*)(A + P->tmp_keys), I(P->tmp_vals),
+    const int gi = (int)(cdiv(n, TPB) < 8192 ? cdiv(n, TPB) : 8192);        // one row per thread: the insert is a chain of atomics
+    hipLaunchKernelGGL(k_insert_bbox, dim3(gi), dim3(TPB), 0, st, coords, n_dev, n, (u64*)(A + P->tmp_keys), I(P->tmp_vals),
                        (unsigned)cap - 1, slot_of_row, status, plan);
     int rc = coords_number_first(slot_of_row, I(P->tmp_vals), n_dev, n, scan_tmp, newid, first_row, n_unique, status, st);
     if (rc != PBN_OK) return rc;
