@@ -82,7 +82,8 @@ def build_scene(copies, dtype, device, workload="c2"):
     batch, teacher, info = synth.make_val_batch(copies=copies, **WORKLOADS[workload])
     b = {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
     b["feat_voxel"] = b["feat_voxel"].to(dtype)
-    t = {k: torch.from_numpy(v).to(device) for k, v in teacher.items()}
+    # the teacher-forced head outputs stand in for slabs the path itself would hold in `dtype`: resident in that dtype
+    t = {k: torch.from_numpy(v).to(device).to(dtype) for k, v in teacher.items()}
     return b, t, info, (batch, teacher)
 
 
