@@ -751,6 +751,7 @@ struct Workspace {
     int *seg_off, *seg_of_pt, *slot_of_pt, *hcount, *hstart, *hcursor, *sseg, *sslot, *cell_rep, *parent, *lab, *root, *semseed, *size,
         *keep, *newid, *lab2, *clt_seg, *last_assigned, *fsize, *noise_flag, *noise_pos, *noise_list, *scan_tmp,
         *scalars, *mstart_tmp;
+    unsigned long long* scan_state[4];
     unsigned long long* hkeys;
     float4 *spt, *cand;
     unsigned hcap;
@@ -768,6 +769,8 @@ size_t carve(Carver& cv, Workspace& w, int n, int n_seg, int general) {
     w.hcap = hash_capacity(n);
     // zero-filled block (one memset): scalars | hcount | hcursor | size | fsize
     w.scalars = cv.take<int>(64);
+    for (int j = 0; j < 4; ++j)          // states of the four chained scans (zeroed with the block)
+        w.scan_state[j] = cv.take<unsigned long long>(scan_chained_state_words((long long)(w.hcap > N ? w.hcap : N)));
     w.hcount = cv.take<int>(w.hcap);
     w.hcursor = cv.take<int>(w.hcap);
     w.size = cv.take<int>(N);
@@ -871,7 +874,7 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(64), 0, stream, seg_len, n_seg, n, capacity, w.seg_off, status);
     hipLaunchKernelGGL(k_cell_insert, dim3(nb), dim3(TPB), 0, stream, off_xyz, sem, w.seg_off, n_seg, nr, inv_cell,
                        w.hkeys, w.hcount, hmask, w.slot_of_pt, w.seg_of_pt, status);
-    int rc = scan_exclusive_i32(w.hcount, w.hstart, (int)w.hcap, w.scan_tmp, nullptr, stream);
+    int rc = scan_exclusive_i32_chained(w.hcount, w.hstart, (int)w.hcap, w.scan_state[0], nullptr, status, stream);
     if (rc != PBN_OK) return rc;
     hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(TPB), 0, stream, off_xyz, nr, w.slot_of_pt, w.hstart, w.hcursor,
                        w.seg_of_pt, w.spt, w.sseg, w.sslot);
@@ -892,21 +895,21 @@ extern "C" int pbn_binary_cluster(const float* off_xyz, const float* org_xyz, co
                        w.hstart, w.hcount, sem, general, w.semseed, w.root, w.lab, w.cell_rep);
     hipLaunchKernelGGL(k_sizes, dim3(nb), dim3(TPB), 0, stream, w.lab, nr, w.size);
     hipLaunchKernelGGL(k_keep, dim3(nb), dim3(TPB), 0, stream, w.lab, w.size, sem, nr, para_f, w.keep);
-    rc = scan_exclusive_i32(w.keep, w.newid, n, w.scan_tmp, total_kept, stream);
+    rc = scan_exclusive_i32_chained(w.keep, w.newid, n, w.scan_state[1], total_kept, status, stream);
     if (rc != PBN_OK) return rc;
     hipLaunchKernelGGL(k_relabel, dim3(nb), dim3(TPB), 0, stream, w.lab, w.keep, w.newid, sem, w.seg_of_pt, org_xyz, nr,
                        w.lab2, cluster_id, clt_sem, w.clt_seg, w.last_assigned, w.fsize, w.noise_flag, w.cand, w.size);
     hipLaunchKernelGGL(k_cluster_num, dim3(cdiv(n_seg, 64)), dim3(64), 0, stream, w.newid, w.seg_off, n_seg, nr,
                        total_kept, cluster_num, status, n_clusters);
     if (nv_flag) {
-        rc = scan_exclusive_i32(w.noise_flag, w.noise_pos, n, w.scan_tmp, n_noise, stream);
+        rc = scan_exclusive_i32_chained(w.noise_flag, w.noise_pos, n, w.scan_state[2], n_noise, status, stream);
         if (rc != PBN_OK) return rc;
         hipLaunchKernelGGL(k_compact_noise, dim3(nb), dim3(TPB), 0, stream, w.noise_flag, w.noise_pos, nr, w.noise_list);
         hipLaunchKernelGGL(k_noise_nn, dim3(cdiv((long long)n * 64, TPB)), dim3(TPB), 0, stream, w.noise_list, n_noise, w.cand, sem, w.seg_of_pt,
                            w.seg_off, w.lab2, w.last_assigned, cluster_id, w.fsize);
     }
     int* mstart = member_start ? member_start : w.mstart_tmp;
-    rc = scan_exclusive_i32(w.fsize, mstart, n, w.scan_tmp, total_assigned, stream);
+    rc = scan_exclusive_i32_chained(w.fsize, mstart, n, w.scan_state[3], total_assigned, status, stream);
     if (rc != PBN_OK) return rc;
     hipLaunchKernelGGL(k_member_tail, dim3(1), dim3(64), 0, stream, mstart, total_assigned, n, total_kept);
     const int center_blocks = 2048;  // one wave per cluster, persistent over clusters

@@ -166,6 +166,81 @@ int fill_ranges(const FillRange* ranges, int n, hipStream_t stream) {
     return PBN_OK;
 }
 
+// Single-launch form: a chained (decoupled look-back) scan over the workgroups.  state = one 64-bit word per workgroup,
+// flag << 32 | value (flag 1: the workgroup's own sum, 2: the inclusive prefix over workgroups 0..b) + a ticket word, all
+// ZEROED by the caller before the launch; every word is written by ONE agent-scope atomic store (payload and flag share the
+// 8-byte granule: no fences), read by agent-scope atomic loads, 64 predecessors per poll (lane j looks at workgroup p - j);
+// polls are bounded: a scan that gives up raises *status bit 16 instead of spinning.
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_chained(const int* in, int* out, int n, unsigned long long* state,
+                                                               int* ticket, int* __restrict__ total, int* __restrict__ status) {
+    __shared__ int wtot[SCAN_THREADS / 64];
+    __shared__ int s_blk, s_ex;
+    if (threadIdx.x == 0) s_blk = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int blk = s_blk;
+    const long long base = (long long)blk * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const long long i = base + k;
+        v[k] = (i < n) ? in[i] : 0;
+        s += v[k];
+    }
+    int tot;
+    const int ex_in_block = block_excl_scan(s, wtot, tot);
+    const int lane = lane_id();
+    if (threadIdx.x < 64) {
+        if (lane == 0)
+            __hip_atomic_store(state + blk, (blk == 0 ? 2ull : 1ull) << 32 | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ex = 0, p = blk - 1;
+        unsigned spins = 0;
+        while (p >= 0) {
+            const int pp = p - lane;
+            const unsigned long long w = pp >= 0 ? __hip_atomic_load(state + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            const bool ready = pp < 0 || (w >> 32) != 0;
+            const unsigned long long not_ready = __ballot(!ready), is_prefix = __ballot(pp >= 0 && (w >> 32) == 2);
+            int upto = not_ready ? __ffsll((long long)not_ready) - 1 : 64;
+            bool stop = false;
+            if (is_prefix) { const int fp = __ffsll((long long)is_prefix) - 1; if (fp < upto) { upto = fp + 1; stop = true; } }
+            ex += wave_reduce_add((lane < upto && pp >= 0) ? (int)(unsigned)w : 0);
+            if (stop) break;
+            if (upto == 0) {
+                if (++spins > (1u << 24)) { if (lane == 0 && status) atomicOr(status, 16); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            p -= upto;
+        }
+        if (lane == 0) {
+            if (blk > 0)
+                __hip_atomic_store(state + blk, 2ull << 32 | (unsigned)(ex + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ex = ex;
+        }
+    }
+    __syncthreads();
+    int ex = s_ex + ex_in_block;
+    if (total && threadIdx.x == SCAN_THREADS - 1 && (long long)(blk + 1) * SCAN_TILE >= n && (long long)blk * SCAN_TILE < n)
+        *total = ex + s;                                   // the last workgroup that holds elements: its last thread's inclusive sum
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const long long i = base + k;
+        if (i < n) out[i] = ex;
+        ex += v[k];
+    }
+}
+
+size_t scan_chained_state_words(long long n) { return (size_t)cdiv(n, SCAN_TILE) + 2; }   // 64-bit words: states + ticket
+
+int scan_exclusive_i32_chained(const int* in, int* out, int n, unsigned long long* state_zeroed, int* total, int* status,
+                               hipStream_t stream) {
+    if (n <= 0) return PBN_OK;                             // *total was zeroed with the state by the caller
+    const int nb = cdiv(n, SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_chained, dim3(nb), dim3(SCAN_THREADS), 0, stream, in, out, n, state_zeroed,
+                       (int*)(state_zeroed + nb), total, status);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
+
 int scan_exclusive_i32(const int* in, int* out, int n, int* tmp, int* total, hipStream_t stream) {
     if (n <= 0) {
         if (total) { const int frc_ = fill_bytes(total, 0, sizeof(int), stream); if (frc_ != PBN_OK) return frc_; }

@@ -68,6 +68,10 @@ static inline size_t scan_tmp_ints(long long n) { return (size_t)cdiv(n, SCAN_TI
 
 // out[i] = sum_{j<i} in[j] for i in [0,n); if total != nullptr, *total = sum of all.  in may alias out.
 int scan_exclusive_i32(const int* in, int* out, int n, int* tmp, int* total, hipStream_t stream);
+// the same in ONE launch (chained scan over the workgroups); state: scan_chained_state_words(n) 64-bit words zeroed by the caller
+size_t scan_chained_state_words(long long n);
+int scan_exclusive_i32_chained(const int* in, int* out, int n, unsigned long long* state_zeroed, int* total, int* status,
+                               hipStream_t stream);
 
 // coords.hip: every cube map of a pyramid in one launch (see the definition)
 struct MapJobs {
