@@ -287,12 +287,14 @@ int pbn_rulebook_pair_fill_dev(const int32_t* nbr, int n, int n_offsets, const i
  * kernel (reached from train.py:57 loss.backward()):  dw[k, ci, co] = sum over the pairs (i, o) of offset k of
  * x[i, ci] * g[o, co].  in_idx / out_idx / seg_begin: the lists of pbn_rulebook_pair_fill, seg_begin int32[K+1] = first
  * `segment`-pair segment of every offset, read on the DEVICE (with lists n_pairs_total only sizes the pair splits: an estimate
- * will do); all three NULL = identity pairs (1x1 convolution / linear layer; n_offsets 1, n_pairs_total rows).  x [*, ld_x], g [*, ld_g] of `dtype` (widened exactly), dw f32[K, cin, cout], any cin / cout.
+ * will do); pair_counts int32[K] (device, may be NULL) = pairs of every offset: without it a workgroup walks the -1 padding of
+ * its offset's last segment as well (a stride-16 level holds ~450 pairs per offset in segments of 4096); all lists NULL = identity pairs (1x1 convolution / linear layer; n_offsets 1, n_pairs_total rows).  x [*, ld_x], g [*, ld_g] of `dtype` (widened exactly), dw f32[K, cin, cout], any cin / cout.
  * fp32 accumulation in a fixed order (deterministic).  workspace: pbn_spconv_wgrad_workspace_bytes (pair splits). */
 size_t pbn_spconv_wgrad_workspace_bytes(int n_offsets, int cin, int cout);
 int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g, int dtype, const int64_t* in_idx,
-                     const int64_t* out_idx, const int32_t* seg_begin, int segment, int n_pairs_total, int n_offsets,
-                     int cin, int cout, float* dw, void* workspace, size_t workspace_bytes, pbn_stream_t stream);
+                     const int64_t* out_idx, const int32_t* seg_begin, const int32_t* pair_counts, int segment,
+                     int n_pairs_total, int n_offsets, int cin, int cout, float* dw, void* workspace, size_t workspace_bytes,
+                     pbn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Capacity-planned inference (csrc/plan.hip): the data-dependent sizes of PBNet.forward stay on the device.  Every buffer

@@ -260,7 +260,7 @@ def rulebook_pairs(nbr, segment=WGRAD_PAIR_SEGMENT):
     seg_begin_d = torch.from_numpy(seg_begin).to(dev)
     N.check(lib.pbn_rulebook_pair_fill(N.ptr(nbr), v, k, N.ptr(table), N.ptr(seg_begin_d), segment,
                                        n_seg, N.ptr(in_idx), N.ptr(out_idx), N.ptr(seg_offset), st), "pbn_rulebook_pair_fill")
-    hit = (in_idx, out_idx, seg_offset, n_seg, segment, seg_begin_d)
+    hit = (in_idx, out_idx, seg_offset, n_seg, segment, seg_begin_d, totals)
     try:
         nbr._pbn_pairs = hit
     except AttributeError:
@@ -271,7 +271,8 @@ def rulebook_pairs(nbr, segment=WGRAD_PAIR_SEGMENT):
 def rulebook_pairs_dev(nbr, segment=WGRAD_PAIR_SEGMENT):
     """rulebook_pairs without the read-back: the lists are sized for the worst case (rows x offsets / segment + offsets
     segments), the per-offset segment ranges are computed on the device (pbn_rulebook_pair_fill_dev) and only consumers
-    that read `seg_begin` on the device (pbn_spconv_wgrad) may use them.  -> (in_idx, out_idx, seg_begin, capacity)."""
+    that read `seg_begin` on the device (pbn_spconv_wgrad) may use them.  -> (in_idx, out_idx, seg_begin, pair counts per
+    offset (device))."""
     hit = getattr(nbr, "_pbn_pairs_dev", None)
     if hit is not None and hit[4] == segment:
         return hit[:4]
@@ -291,7 +292,7 @@ def rulebook_pairs_dev(nbr, segment=WGRAD_PAIR_SEGMENT):
     seg_begin = torch.empty(k + 1, dtype=torch.int32, device=dev)
     N.check(lib.pbn_rulebook_pair_fill_dev(N.ptr(nbr), v, k, N.ptr(table), N.ptr(totals), segment, N.ptr(seg_begin),
                                            N.ptr(in_idx), N.ptr(out_idx), N.ptr(seg_offset), st), "pbn_rulebook_pair_fill_dev")
-    hit = (in_idx, out_idx, seg_begin, cap, segment)
+    hit = (in_idx, out_idx, seg_begin, totals, segment)
     try:
         nbr._pbn_pairs_dev = hit
     except AttributeError:
@@ -314,11 +315,11 @@ def wgrad_native(feats, grad_out, nbr, cin, cout):
     if int(feats.shape[0]) == 0 or int(grad_out.shape[0]) == 0:     # an empty level: no pairs, the gradient is zero
         return torch.zeros(1 if nbr is None else int(nbr.shape[1]), cin, cout, dtype=torch.float32, device=dev)
     if nbr is None:
-        k, in_idx, out_idx, seg_begin, n_pairs = 1, None, None, None, int(feats.shape[0])
+        k, in_idx, out_idx, seg_begin, counts, n_pairs = 1, None, None, None, None, int(feats.shape[0])
     else:
         assert nbr.is_contiguous()
         k = int(nbr.shape[1])
-        in_idx, out_idx, seg_begin, _ = rulebook_pairs_dev(nbr)      # no read-back: the segment ranges stay on the device
+        in_idx, out_idx, seg_begin, counts = rulebook_pairs_dev(nbr)   # no read-back: segment ranges and pair counts stay on the device
         # the host only needs the pair count to choose the number of pair splits (too few splits = too few workgroups, too
         # many = more partial slabs): half the table populated for cubes (the bench scene's stride-2..16 levels hold 12-16 of
         # 27, stride 1 7.6 -- where the split count is bounded by the workgroup target anyway), a quarter for the k=2 maps
@@ -326,7 +327,7 @@ def wgrad_native(feats, grad_out, nbr, cin, cout):
     dw = torch.empty(k, cin, cout, dtype=torch.float32, device=dev)
     ws = _WGRAD_WS.get(dev, int(lib.pbn_spconv_wgrad_workspace_bytes(k, cin, cout)))
     rc = lib.pbn_spconv_wgrad(N.c_vp(feats.data_ptr()), feats.stride(0), N.c_vp(grad_out.data_ptr()), grad_out.stride(0),
-                              _DT[feats.dtype], N.ptr(in_idx), N.ptr(out_idx), N.ptr(seg_begin),
+                              _DT[feats.dtype], N.ptr(in_idx), N.ptr(out_idx), N.ptr(seg_begin), N.ptr(counts),
                               WGRAD_PAIR_SEGMENT if nbr is not None else 0, n_pairs, k, int(cin), int(cout), N.ptr(dw),
                               N.c_vp(ws.data_ptr()), ws.numel(), N.current_stream())
     N.check(rc, "pbn_spconv_wgrad")

@@ -73,7 +73,7 @@ SIGNATURES = {
     "pbn_spconv_forward": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_i32p, c_int, c_vp, c_int, c_int, c_int,
                                    c_f32p, c_f32p, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "pbn_spconv_wgrad_workspace_bytes": (c_size, [c_int, c_int, c_int]),
-    "pbn_spconv_wgrad": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_i32p, c_int, c_int, c_int, c_int, c_int,
+    "pbn_spconv_wgrad": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_int,
                                  c_f32p, c_vp, c_size, c_vp]),
     "pbn_gather_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "pbn_segment_pool_workspace_bytes": (c_size, [c_int, c_int]),
@@ -195,9 +195,15 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_torch_C = None
+
+
 def current_stream():
-    import torch
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    global _torch_C
+    if _torch_C is None:
+        import torch
+        _torch_C = torch._C
+    return ctypes.c_void_p(_torch_C._cuda_getCurrentRawStream(_torch_C._cuda_getDevice()))
 
 
 def require_cuda(*tensors):

@@ -14,11 +14,13 @@ class StreamScratch(object):
 
     def get(self, device, nbytes, min_bytes=0):
         """A uint8 block of at least `nbytes` owned by (device, current stream); grown on demand."""
-        if torch.cuda.is_current_stream_capturing():
+        # (the raw C entry points: torch.cuda.current_stream() builds a Stream object per call, ~7 us of the wrappers' ~20)
+        if torch._C._cuda_isCurrentStreamCapturing():
             # inside a HIP-graph capture: a cached block would belong to THIS graph's private pool and be handed to the
             # next capture on torch's shared capture stream (use after free once this graph is released): allocate per call
             return torch.empty(max(int(nbytes), int(min_bytes)), dtype=torch.uint8, device=device)
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        index = device.index if isinstance(device, torch.device) and device.index is not None else torch._C._cuda_getDevice()
+        key = (index, torch._C._cuda_getCurrentRawStream(index))
         with self._lock:
             ws = self._table.get(key)
             if ws is not None and ws.numel() >= nbytes:

@@ -37,7 +37,7 @@ for level, cin, cout in ((4, 256, 256), (3, 256, 256), (3, 128, 128), (2, 128, 1
 
     def exact(n_pairs=n_seg * C.WGRAD_PAIR_SEGMENT):
         N.check(lib.pbn_spconv_wgrad(N.c_vp(x.data_ptr()), cin, N.c_vp(g.data_ptr()), cout, 1, N.ptr(in_idx), N.ptr(out_idx),
-                                     N.ptr(seg_begin), C.WGRAD_PAIR_SEGMENT, n_pairs, 27, cin, cout, N.ptr(dw),
+                                     N.ptr(seg_begin), None, C.WGRAD_PAIR_SEGMENT, n_pairs, 27, cin, cout, N.ptr(dw),
                                      N.c_vp(ws.data_ptr()), ws.numel(), N.current_stream()), "wgrad")
     t_exact = timed(exact)
     ref = dw.clone()
