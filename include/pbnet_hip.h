@@ -520,6 +520,61 @@ int pbn_unet_forward_timed(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf
                            const int32_t* const* down, const int32_t* const* up, void* arena, size_t arena_bytes,
                            int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream, float* op_ms);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Native TRAINING executor of a MinkUNet body (csrc/train_exec.hip): the train-mode forward of
+ * /root/reference/network/Mink.py:291-350 (every convolution but the final 1x1: conv -> bn -> relu, the BasicBlocks with
+ * their shortcuts, the skip concatenations written in place) and its backward as ONE call each -- the sequencing that
+ * MinkowskiEngine/fused_train.py does from Python in ~330 native calls per network and direction (configs[2] was host-bound).
+ * Same kernels, same order, same arithmetic as that path: pbn_spconv_forward (convolutions and input gradients),
+ * pbn_bn_act_train_* (batch norm with its tail), pbn_spconv_wgrad.
+ *   op       : convolution in (buf, col) -> pre_buf, then y = act(bn(pre) [+ res]) -> (out_buf, out_col).  Buffers are the
+ *              pbn_unet_buf list (buffer 0 = the caller's input slab); pbn_unet_arena_bytes lays out BOTH arenas: the
+ *              activations (kept for the backward) and, with the same offsets, their gradients.
+ *   backward : ops in reverse; the caller has written d(loss)/d(output) into the gradient arena at the output buffer.
+ *              dx_accumulate = the gradient of the input view already holds a contribution (a skip, a shortcut): the input
+ *              gradient is then added in the convolution's epilogue (residual = out).  The residual gradient of a block is
+ *              WRITTEN by the batch-norm backward, so it must be the first contribution of its buffer (the planner checks).
+ *   pairs    : the weight gradient's pair lists per map (pbn_rulebook_pair_fill_dev): index 0..4 = k3 of levels 0..4,
+ *              5 = k5, 6..9 = down of fine levels 0..3, 10..13 = up of fine levels 0..3; entries of unused maps may be zero.
+ *   stats    : f32, per op [mean | invstd] at stat_off; param_grads: f32, per op dW [K, cin, cout] at dw_off, dgamma /
+ *              dbeta at their offsets (all in floats). */
+typedef struct {
+    int32_t map_kind, level_in, level_out;
+    int32_t in_buf, in_col, pre_buf, res_buf, res_col, out_buf, out_col;
+    int32_t relu, cin, cout;
+    int32_t vpo, n_steps, cout_p;            /* forward weights (pbn_pack_weight) */
+    int32_t vpo_d, n_steps_d, cout_p_d;      /* input-gradient weights (offsets mirrored for cubes, channel roles swapped) */
+    int32_t want_dx, dx_accumulate, _pad;
+    const void* w;
+    const void* w_d;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;                      /* NULL: statistics not tracked */
+    float* running_var;
+    float eps, momentum;
+    int64_t stat_off, dw_off, dgamma_off, dbeta_off;
+} pbn_train_op;
+
+typedef struct {
+    const int64_t* in_idx;
+    const int64_t* out_idx;
+    const int32_t* seg_begin;
+    const int32_t* counts;
+    int32_t segment, n_pairs_estimate;
+} pbn_pair_lists;
+
+int pbn_unet_train_forward(const pbn_train_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows,
+                           const void* input, int ld_input, const int32_t* const* k3, const int32_t* k5,
+                           const int32_t* const* down, const int32_t* const* up, void* act_arena, size_t arena_bytes,
+                           float* stats, int dtype, void* splitk_ws, size_t splitk_bytes, void* bn_ws, size_t bn_ws_bytes,
+                           pbn_stream_t stream);
+int pbn_unet_train_backward(const pbn_train_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows,
+                            const void* input, int ld_input, const int32_t* const* k3, const int32_t* k5,
+                            const int32_t* const* down, const int32_t* const* up, const pbn_pair_lists* pairs,
+                            const void* act_arena, void* grad_arena, size_t arena_bytes, const float* stats,
+                            float* param_grads, void* dinput, int ld_dinput, int dtype, void* splitk_ws, size_t splitk_bytes,
+                            void* bn_ws, size_t bn_ws_bytes, void* wgrad_ws, size_t wgrad_ws_bytes, pbn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,25 @@ class UnetBuf(ctypes.Structure):
     _fields_ = [("level", c_i32), ("width", c_i32)]
 
 
+class TrainOp(ctypes.Structure):
+    """pbn_train_op (include/pbnet_hip.h)."""
+    _fields_ = [("map_kind", c_i32), ("level_in", c_i32), ("level_out", c_i32),
+                ("in_buf", c_i32), ("in_col", c_i32), ("pre_buf", c_i32), ("res_buf", c_i32), ("res_col", c_i32),
+                ("out_buf", c_i32), ("out_col", c_i32), ("relu", c_i32), ("cin", c_i32), ("cout", c_i32),
+                ("vpo", c_i32), ("n_steps", c_i32), ("cout_p", c_i32), ("vpo_d", c_i32), ("n_steps_d", c_i32),
+                ("cout_p_d", c_i32), ("want_dx", c_i32), ("dx_accumulate", c_i32), ("_pad", c_i32),
+                ("w", ctypes.c_void_p), ("w_d", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+                ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p), ("eps", ctypes.c_float),
+                ("momentum", ctypes.c_float), ("stat_off", ctypes.c_int64), ("dw_off", ctypes.c_int64),
+                ("dgamma_off", ctypes.c_int64), ("dbeta_off", ctypes.c_int64)]
+
+
+class PairLists(ctypes.Structure):
+    """pbn_pair_lists (include/pbnet_hip.h)."""
+    _fields_ = [("in_idx", ctypes.c_void_p), ("out_idx", ctypes.c_void_p), ("seg_begin", ctypes.c_void_p),
+                ("counts", ctypes.c_void_p), ("segment", c_i32), ("n_pairs_estimate", c_i32)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/pbnet_hip.h (tests/test_abi.py checks this)
 SIGNATURES = {
     "pbn_version": (ctypes.c_char_p, []),
@@ -145,6 +164,14 @@ SIGNATURES = {
     "pbn_unet_forward": (c_int, [ctypes.POINTER(UnetOp), c_int, ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32),
                                  c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp, ctypes.POINTER(ctypes.c_void_p),
                                  ctypes.POINTER(ctypes.c_void_p), c_vp, c_size, c_int, c_vp, c_size, c_vp]),
+    "pbn_unet_train_forward": (c_int, [ctypes.POINTER(TrainOp), c_int, ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32),
+                                       c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp, ctypes.POINTER(ctypes.c_void_p),
+                                       ctypes.POINTER(ctypes.c_void_p), c_vp, c_size, c_vp, c_int, c_vp, c_size, c_vp, c_size,
+                                       c_vp]),
+    "pbn_unet_train_backward": (c_int, [ctypes.POINTER(TrainOp), c_int, ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32),
+                                        c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp, ctypes.POINTER(ctypes.c_void_p),
+                                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(PairLists), c_vp, c_vp, c_size, c_vp,
+                                        c_vp, c_vp, c_int, c_int, c_vp, c_size, c_vp, c_size, c_vp, c_size, c_vp]),
     "pbn_unet_forward_timed": (c_int, [ctypes.POINTER(UnetOp), c_int, ctypes.POINTER(UnetBuf), c_int,
                                        ctypes.POINTER(c_i32), c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp,
                                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_vp, c_size,

@@ -106,7 +106,12 @@ class MinkUNet(nn.Module):
         return self._forward_modules(x)
 
     def _forward_modules(self, x):
-        """Mink.py:291-354, module by module."""
+        """Mink.py:291-354, module by module -- or, on the native training path, the whole body as one autograd node
+        (network/train_engine.py) followed by the final 1x1 convolution."""
+        from .train_engine import forward_body
+        body = forward_body(self, x)
+        if body is not None:
+            return self.final_sematic(body)
         out = conv_bn_act(self.conv0p1s1, self.bn0, x)                # = self.relu(self.bn0(self.conv0p1s1(x))), one node when training natively
         skips = [out]
         for i in range(4):
@@ -215,6 +220,8 @@ class MinkUNet(nn.Module):
 
     def _forget_state_tensors(self):
         self.__dict__.pop("_state_tensors", None)
+        self.__dict__.pop("_train_plans", None)
+        self.__dict__.pop("_train_engine_ok", None)
         self._plans.clear()
 
     def _apply(self, fn, *args, **kwargs):

@@ -1,0 +1,115 @@
+"""GPU tier: the native training executor of the MinkUNet body (network/train_engine.py over csrc/train_exec.hip) against the
+module path it replaces (one autograd node per block, MinkowskiEngine/fused_train.py): same kernels in the same order, so
+outputs, running statistics and -- in fp32 -- every gradient agree to the last bit.  With 16-bit slabs the two differ in how
+a gradient with two producers is rounded: where an encoder output feeds both the next down convolution and a skip, autograd
+adds two ROUNDED gradients (round(round(a) + round(b))) while the executor adds in the convolution's fp32 epilogue
+(round(a + round(b))); a block with a 1x1 shortcut adds its two input gradients in the epilogue on both paths, but in the
+opposite order.  The last stage sees identical gradients, the layers before it agree to a few roundings."""
+import numpy as np
+import pytest
+import torch
+
+import pbnet_amd.MinkowskiEngine as ME
+from pbnet_amd import synth
+from pbnet_amd.network import train_engine as TE
+from pbnet_amd.network.Mink import Mink_unet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _coords(seed=61, batch=2):
+    sc = synth.synth_room(seed=seed, pitch=0.0225, room=(0.7, 0.5, 0.4), n_boxes=1)
+    q, _, _ = synth.voxelize_numpy(sc["xyz"], 0.02)
+    parts = [np.concatenate([np.full((len(q), 1), b, np.int32), q + np.array([9 * b, 0, 0], np.int32)], 1) for b in range(batch)]
+    return np.concatenate(parts, 0).astype(np.int32)
+
+
+def _step(net, feats, coords, target, engine, want_dx):
+    TE.ENABLED = engine
+    for p in net.parameters():
+        p.grad = None
+    x = feats.clone().requires_grad_(want_dx)
+    out = net(ME.SparseTensor(x, torch.from_numpy(coords).to(DEV))).F
+    loss = ((out.float() - target) ** 2).mean()
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    bufs = {k: b.detach().clone() for k, b in net.named_buffers()}
+    return out.detach().clone(), (x.grad.detach().clone() if want_dx else None), grads, bufs
+
+
+@pytest.mark.parametrize("arch,dtype,want_dx", [("MinkUNet14A", torch.bfloat16, True), ("MinkUNet34C", torch.bfloat16, False),
+                                                ("MinkUNet14A", torch.float32, True), ("MinkUNet18A", torch.float16, False)])
+def test_engine_matches_module_path(arch, dtype, want_dx):
+    coords = _coords()
+    torch.manual_seed(5)
+    net = Mink_unet(6, 32, arch=arch).to(DEV).train()
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    feats = torch.randn(len(coords), 6, device=DEV).to(dtype)
+    target = torch.randn(len(coords), 32, device=DEV)
+    try:
+        ref = _step(net, feats, coords, target, False, want_dx)
+        net.load_state_dict(state)
+        got = _step(net, feats, coords, target, True, want_dx)
+        assert net.__dict__.get("_train_plans"), "the executor did not run"
+    finally:
+        TE.ENABLED = True
+    assert torch.equal(got[0], ref[0])
+    for k in ref[3]:
+        assert torch.equal(got[3][k], ref[3][k]), k
+
+    def close(a, b, what):
+        a, b = a.float(), b.float()
+        # one extra bf16 rounding (2^-9) per skip, carried through up to ~20 layers of 16-bit gradients; fp32 is compared exactly
+        assert (a - b).norm().item() <= 4e-2 * max(b.norm().item(), 1e-12), what
+
+    exact_everywhere = dtype == torch.float32
+    behind_skips = ("block8", "final_sematic")
+    if want_dx:
+        assert torch.equal(got[1], ref[1]) if exact_everywhere else close(got[1], ref[1], "input gradient") is None
+    n_exact = 0
+    for k in ref[2]:
+        if exact_everywhere or k.startswith(behind_skips):
+            assert torch.equal(got[2][k], ref[2][k]), k
+            n_exact += 1
+        else:
+            close(got[2][k], ref[2][k], k)
+    assert n_exact >= 8
+
+
+def test_engine_two_steps_with_optimizer():
+    """Weights change between steps (packed forms are refreshed), the plan is reused, losses follow the module path."""
+    coords = _coords(seed=62, batch=1)
+    feats = torch.randn(len(coords), 6, device=DEV).to(torch.bfloat16)
+    target = torch.randn(len(coords), 32, device=DEV)
+    losses = {}
+    try:
+        for engine in (False, True):
+            TE.ENABLED = engine
+            torch.manual_seed(9)
+            net = Mink_unet(6, 32, arch="MinkUNet14A").to(DEV).train()
+            opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+            ls = []
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                out = net(ME.SparseTensor(feats, torch.from_numpy(coords).to(DEV))).F
+                loss = ((out.float() - target) ** 2).mean()
+                loss.backward()
+                opt.step()
+                ls.append(loss.item())
+            losses[engine] = ls
+    finally:
+        TE.ENABLED = True
+    assert losses[True][0] == losses[False][0], losses              # same forward
+    for a, b in zip(losses[True], losses[False]):                    # 16-bit gradients agree to a few roundings (see above)
+        assert abs(a - b) <= 5e-3 * abs(b), losses
+    assert losses[True][2] < losses[True][0]
+
+
+def test_engine_eval_and_no_grad_fall_back():
+    coords = _coords(seed=63, batch=1)
+    net = Mink_unet(6, 32, arch="MinkUNet14A").to(DEV).train()
+    feats = torch.randn(len(coords), 6, device=DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        net(ME.SparseTensor(feats, torch.from_numpy(coords).to(DEV)))
+    assert not net.__dict__.get("_train_plans")
