@@ -278,10 +278,27 @@ int pbn_rulebook_pair_fill(const int32_t* nbr, int n, int n_offsets, const int32
 /* pbn_rulebook_pair_fill_dev -- the same lists with NO host knowledge of the pair counts (no read-back between
  * pbn_rulebook_pair_counts and the fill: a training step builds ~40 maps): seg_begin int32[n_offsets + 1] is computed on the
  * device from `totals`, in_idx / out_idx / seg_offset must hold the worst case of n * n_offsets / segment + n_offsets
- * segments, only the segments below seg_begin[n_offsets] are written (tails padded with -1) and may be read. */
+ * segments, only the segments below seg_begin[n_offsets] are written and may be read.  The tail of an offset's last segment
+ * is NOT padded: the consumer bounds every offset by its pair count (pbn_spconv_wgrad: pair_counts = `totals`).  One launch
+ * (every block derives seg_begin from the totals itself); n_offsets <= 512. */
 int pbn_rulebook_pair_fill_dev(const int32_t* nbr, int n, int n_offsets, const int32_t* table, const int32_t* totals,
                                int segment, int32_t* seg_begin, int64_t* in_idx, int64_t* out_idx, int64_t* seg_offset,
                                pbn_stream_t stream);
+
+/* pbn_rulebook_pairs_multi -- counts + device-side fill (the two calls above) of up to 16 maps in THREE launches: the
+ * training executor needs the lists of all 14 maps of a lineage, most of them small (a launch costs more than their work).
+ * Per job the buffers of pbn_rulebook_pair_counts / _fill_dev (table int32[max(pbn_rulebook_pair_blocks(n), 1) * n_offsets]). */
+typedef struct {
+    const int32_t* nbr;
+    int32_t n, n_offsets;
+    int32_t* table;
+    int32_t* totals;
+    int32_t* seg_begin;
+    int64_t* in_idx;
+    int64_t* out_idx;
+    int64_t* seg_offset;
+} pbn_pair_job;
+int pbn_rulebook_pairs_multi(const pbn_pair_job* jobs, int n_jobs, int segment, pbn_stream_t stream);
 
 /* Weight gradient of the sparse convolution on the matrix cores (csrc/wgrad.hip), ME's convolution backward w.r.t. the
  * kernel (reached from train.py:57 loss.backward()):  dw[k, ci, co] = sum over the pairs (i, o) of offset k of

@@ -300,6 +300,38 @@ def rulebook_pairs_dev(nbr, segment=WGRAD_PAIR_SEGMENT):
     return hit[:4]
 
 
+def rulebook_pairs_dev_multi(maps, segment=WGRAD_PAIR_SEGMENT):
+    """rulebook_pairs_dev of several maps in three launches (pbn_rulebook_pairs_multi; maps whose lists exist are skipped);
+    the results are cached on the map tensors exactly as rulebook_pairs_dev caches them."""
+    todo = [m for m in maps if getattr(m, "_pbn_pairs_dev", None) is None or m._pbn_pairs_dev[4] != segment]
+    lib = N.lib()
+    for i in range(0, len(todo), 16):
+        group = todo[i:i + 16]
+        jobs = (N.PairJob * len(group))()
+        keep = []
+        for j, nbr in enumerate(group):
+            N.require_cuda(nbr)
+            assert nbr.dtype == torch.int32 and nbr.is_contiguous()
+            v, k = int(nbr.shape[0]), int(nbr.shape[1])
+            dev = nbr.device
+            table = torch.empty(max(lib.pbn_rulebook_pair_blocks(v), 1) * k, dtype=torch.int32, device=dev)
+            totals = torch.empty(k, dtype=torch.int32, device=dev)
+            cap = (v * k) // segment + k
+            in_idx = torch.empty(cap * segment, dtype=torch.int64, device=dev)
+            out_idx = torch.empty(cap * segment, dtype=torch.int64, device=dev)
+            seg_offset = torch.empty(cap, dtype=torch.int64, device=dev)
+            seg_begin = torch.empty(k + 1, dtype=torch.int32, device=dev)
+            q = jobs[j]
+            q.nbr, q.n, q.n_offsets = nbr.data_ptr(), v, k
+            q.table, q.totals, q.seg_begin = table.data_ptr(), totals.data_ptr(), seg_begin.data_ptr()
+            q.in_idx, q.out_idx, q.seg_offset = in_idx.data_ptr(), out_idx.data_ptr(), seg_offset.data_ptr()
+            keep.append((nbr, (in_idx, out_idx, seg_begin, totals, segment), table, seg_offset))
+        N.check(lib.pbn_rulebook_pairs_multi(jobs, len(group), segment, N.current_stream()), "pbn_rulebook_pairs_multi")
+        for nbr, hit, _, _ in keep:
+            nbr._pbn_pairs_dev = hit
+    return [m._pbn_pairs_dev[:4] for m in maps]
+
+
 _WGRAD_WS = StreamScratch()
 
 

@@ -65,6 +65,13 @@ class TrainOp(ctypes.Structure):
                 ("dgamma_off", ctypes.c_int64), ("dbeta_off", ctypes.c_int64)]
 
 
+class PairJob(ctypes.Structure):
+    """pbn_pair_job (include/pbnet_hip.h)."""
+    _fields_ = [("nbr", ctypes.c_void_p), ("n", c_i32), ("n_offsets", c_i32), ("table", ctypes.c_void_p),
+                ("totals", ctypes.c_void_p), ("seg_begin", ctypes.c_void_p), ("in_idx", ctypes.c_void_p),
+                ("out_idx", ctypes.c_void_p), ("seg_offset", ctypes.c_void_p)]
+
+
 class PairLists(ctypes.Structure):
     """pbn_pair_lists (include/pbnet_hip.h)."""
     _fields_ = [("in_idx", ctypes.c_void_p), ("out_idx", ctypes.c_void_p), ("seg_begin", ctypes.c_void_p),
@@ -164,6 +171,7 @@ SIGNATURES = {
     "pbn_unet_forward": (c_int, [ctypes.POINTER(UnetOp), c_int, ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32),
                                  c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp, ctypes.POINTER(ctypes.c_void_p),
                                  ctypes.POINTER(ctypes.c_void_p), c_vp, c_size, c_int, c_vp, c_size, c_vp]),
+    "pbn_rulebook_pairs_multi": (c_int, [ctypes.POINTER(PairJob), c_int, c_int, c_vp]),
     "pbn_unet_train_forward": (c_int, [ctypes.POINTER(TrainOp), c_int, ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32),
                                        c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp, ctypes.POINTER(ctypes.c_void_p),
                                        ctypes.POINTER(ctypes.c_void_p), c_vp, c_size, c_vp, c_int, c_vp, c_size, c_vp, c_size,

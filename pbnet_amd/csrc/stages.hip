@@ -743,17 +743,33 @@ extern "C" int pbn_proposal_rows_dev(const void* mask_score, int ld, float thd, 
 namespace pbn {
 namespace {
 constexpr int PAIR_ROWS = 256;   // rows per block = TPB
+constexpr int PAIR_KC = 32;      // offsets per LDS tile
+constexpr int PAIR_PITCH = PAIR_KC + 1;
+
+// A block owns 256 rows.  The [256 x 32-offset] piece of the table is read ONCE, along the rows (coalesced), into LDS
+// (pitch 33: the column reads below are conflict-free); every wave then owns the columns w, w + 4, ... of the piece and walks
+// its 256 rows as four ballots -- no barrier per offset (round 2 read the table column by column with two barriers each).
+__device__ __forceinline__ void pair_tile_load(const int* __restrict__ nbr, int n, int K, int row0, int k0, int kc, int* s_tile) {
+    for (int e = threadIdx.x; e < PAIR_ROWS * kc; e += TPB) {
+        const int r = e / kc, cc = e - r * kc;
+        s_tile[r * PAIR_PITCH + cc] = row0 + r < n ? nbr[(size_t)(row0 + r) * K + k0 + cc] : -1;
+    }
+}
 
 __global__ __launch_bounds__(TPB) void k_pair_count(const int* __restrict__ nbr, int n, int K, int* __restrict__ table) {
-    __shared__ int s_cnt[4];
-    const int row = blockIdx.x * PAIR_ROWS + threadIdx.x;
-    const int wave = threadIdx.x >> 6;
-    for (int k = 0; k < K; ++k) {
-        const bool hit = row < n && nbr[(size_t)row * K + k] >= 0;
-        const int c = __popcll(__ballot(hit));
-        if ((threadIdx.x & 63) == 0) s_cnt[wave] = c;
+    __shared__ int s_tile[PAIR_ROWS * PAIR_PITCH];
+    const int row0 = blockIdx.x * PAIR_ROWS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k0 = 0; k0 < K; k0 += PAIR_KC) {
+        const int kc = min(PAIR_KC, K - k0);
+        pair_tile_load(nbr, n, K, row0, k0, kc, s_tile);
         __syncthreads();
-        if (threadIdx.x == 0) table[(size_t)blockIdx.x * K + k] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        for (int cc = wave; cc < kc; cc += TPB / 64) {
+            int cnt = 0;
+#pragma unroll
+            for (int sub = 0; sub < PAIR_ROWS / 64; ++sub) cnt += __popcll(__ballot(s_tile[(sub * 64 + lane) * PAIR_PITCH + cc] >= 0));
+            if (lane == 0) table[(size_t)blockIdx.x * K + k0 + cc] = cnt;
+        }
         __syncthreads();
     }
 }
@@ -777,60 +793,165 @@ __global__ __launch_bounds__(64) void k_pair_scan(int* __restrict__ table, int n
     if (lane == 0) totals[k] = run;
 }
 
-__global__ __launch_bounds__(TPB) void k_pair_fill(const int* __restrict__ nbr, int n, int K, const int* __restrict__ table,
-                                                  const int* __restrict__ seg_start, int seg, long long* __restrict__ in_idx,
-                                                  long long* __restrict__ out_idx, long long* __restrict__ seg_offset) {
-    __shared__ int s_cnt[4];
-    const int row = blockIdx.x * PAIR_ROWS + threadIdx.x;
+// seg_start NULL (device lists): every block derives the first segment of every offset from the totals itself (one wave,
+// K <= a few hundred) and block 0 publishes them as seg_begin_out[K + 1] -- no separate launch, no read-back
+__device__ __forceinline__ void pair_fill_body(const int* __restrict__ nbr, int n, int K, const int* __restrict__ table,
+                                               const int* __restrict__ seg_start, const int* __restrict__ totals,
+                                               int* __restrict__ seg_begin_out, int seg, long long* __restrict__ in_idx,
+                                               long long* __restrict__ out_idx, long long* __restrict__ seg_offset, int blk,
+                                               int* s_tile, int* s_seg) {
+    const int row0 = blk * PAIR_ROWS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int k = 0; k < K; ++k) {
-        const int src = row < n ? nbr[(size_t)row * K + k] : -1;
-        const unsigned long long m = __ballot(src >= 0);
-        if (lane == 0) s_cnt[wave] = __popcll(m);
+    if (seg_start) {
+        for (int k = threadIdx.x; k < K; k += TPB) s_seg[k] = seg_start[k];
+    } else if (wave == 0) {
+        int run = 0;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int k = k0 + lane;
+            const int v = k < K ? (totals[k] + seg - 1) / seg : 0;
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            if (k < K) { s_seg[k] = run + inc - v; if (blk == 0) seg_begin_out[k] = run + inc - v; }
+            run += __shfl(inc, 63);
+        }
+        if (lane == 0 && blk == 0) seg_begin_out[K] = run;
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += PAIR_KC) {
+        const int kc = min(PAIR_KC, K - k0);
+        pair_tile_load(nbr, n, K, row0, k0, kc, s_tile);
         __syncthreads();
-        if (src >= 0) {
-            int pos = table[(size_t)blockIdx.x * K + k] + __popcll(m & ((1ULL << lane) - 1ULL));
-            for (int w = 0; w < wave; ++w) pos += s_cnt[w];
-            const int q = pos / seg;
-            const long long slot = (long long)(seg_start[k] + q) * seg + (pos - q * seg);
-            in_idx[slot] = src;
-            out_idx[slot] = row;
-            if (pos == q * seg) seg_offset[seg_start[k] + q] = k;
+        for (int cc = wave; cc < kc; cc += TPB / 64) {
+            const int k = k0 + cc;
+            int pos0 = table[(size_t)blk * K + k];
+            const int first = s_seg[k];
+#pragma unroll
+            for (int sub = 0; sub < PAIR_ROWS / 64; ++sub) {
+                const int src = s_tile[(sub * 64 + lane) * PAIR_PITCH + cc];
+                const unsigned long long m = __ballot(src >= 0);
+                if (src >= 0) {
+                    const int pos = pos0 + __popcll(m & ((1ULL << lane) - 1ULL));
+                    const int q = pos / seg;
+                    const long long slot = (long long)(first + q) * seg + (pos - q * seg);
+                    in_idx[slot] = src;
+                    out_idx[slot] = row0 + sub * 64 + lane;
+                    if (pos == q * seg) seg_offset[first + q] = k;
+                }
+                pos0 += __popcll(m);
+            }
         }
         __syncthreads();
     }
 }
 
-// seg_begin[k] = segments of the offsets before k (one wave; K <= a few hundred)
-__global__ __launch_bounds__(64) void k_pair_segments(const int* __restrict__ totals, int K, int seg, int* __restrict__ seg_begin) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(TPB) void k_pair_fill(const int* __restrict__ nbr, int n, int K, const int* __restrict__ table,
+                                                  const int* __restrict__ seg_start, const int* __restrict__ totals,
+                                                  int* __restrict__ seg_begin_out, int seg, long long* __restrict__ in_idx,
+                                                  long long* __restrict__ out_idx, long long* __restrict__ seg_offset) {
+    __shared__ int s_tile[PAIR_ROWS * PAIR_PITCH];
+    __shared__ int s_seg[512];
+    pair_fill_body(nbr, n, K, table, seg_start, totals, seg_begin_out, seg, in_idx, out_idx, seg_offset, blockIdx.x, s_tile, s_seg);
+}
+
+
+// ---- all maps of a pyramid in three launches (the training executor builds 14 lists per lineage; most maps are small and
+// a launch costs more than their work): a job table by value, blocks -> jobs through the prefix of their block counts -------
+constexpr int PAIR_MAX_JOBS = 16;
+struct PairJobs {
+    const int* nbr[PAIR_MAX_JOBS]; int* table[PAIR_MAX_JOBS]; int* totals[PAIR_MAX_JOBS]; int* seg_begin[PAIR_MAX_JOBS];
+    long long* in_idx[PAIR_MAX_JOBS]; long long* out_idx[PAIR_MAX_JOBS]; long long* seg_offset[PAIR_MAX_JOBS];
+    int n[PAIR_MAX_JOBS], K[PAIR_MAX_JOBS];
+    int block_begin[PAIR_MAX_JOBS + 1];      // row blocks (count / fill)
+    int col_begin[PAIR_MAX_JOBS + 1];        // columns (scan)
+    int n_jobs, seg;
+};
+__device__ __forceinline__ int pair_job_of(const int* begin, int n_jobs, int b) {
+    int j = 0;
+    while (j + 1 < n_jobs && b >= begin[j + 1]) ++j;
+    return j;
+}
+
+__device__ __forceinline__ void pair_count_body(const int* __restrict__ nbr, int n, int K, int* __restrict__ table, int blk, int* s_tile) {
+    const int row0 = blk * PAIR_ROWS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k0 = 0; k0 < K; k0 += PAIR_KC) {
+        const int kc = min(PAIR_KC, K - k0);
+        pair_tile_load(nbr, n, K, row0, k0, kc, s_tile);
+        __syncthreads();
+        for (int cc = wave; cc < kc; cc += TPB / 64) {
+            int cnt = 0;
+#pragma unroll
+            for (int sub = 0; sub < PAIR_ROWS / 64; ++sub) cnt += __popcll(__ballot(s_tile[(sub * 64 + lane) * PAIR_PITCH + cc] >= 0));
+            if (lane == 0) table[(size_t)blk * K + k0 + cc] = cnt;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(TPB) void k_pair_count_multi(const PairJobs J) {
+    __shared__ int s_tile[PAIR_ROWS * PAIR_PITCH];
+    const int j = pair_job_of(J.block_begin, J.n_jobs, blockIdx.x);
+    pair_count_body(J.nbr[j], J.n[j], J.K[j], J.table[j], blockIdx.x - J.block_begin[j], s_tile);
+}
+__global__ __launch_bounds__(64) void k_pair_scan_multi(const PairJobs J) {
+    const int j = pair_job_of(J.col_begin, J.n_jobs, blockIdx.x);
+    const int k = blockIdx.x - J.col_begin[j], lane = threadIdx.x, K = J.K[j];
+    const int n_blocks = J.block_begin[j + 1] - J.block_begin[j];
+    int* table = J.table[j];
     int run = 0;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        const int k = k0 + lane;
-        const int v = k < K ? (totals[k] + seg - 1) / seg : 0;
+    for (int b0 = 0; b0 < n_blocks; b0 += 64) {
+        const int b = b0 + lane;
+        const int v = b < n_blocks ? table[(size_t)b * K + k] : 0;
         int inc = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int t = __shfl_up(inc, o);
             if (lane >= o) inc += t;
         }
-        if (k < K) seg_begin[k] = run + inc - v;
+        if (b < n_blocks) table[(size_t)b * K + k] = run + inc - v;
         run += __shfl(inc, 63);
     }
-    if (lane == 0) seg_begin[K] = run;
+    if (lane == 0) J.totals[j][k] = run;
 }
-
-// -1 into the unused tail of every offset's last segment (at most seg - 1 slots per offset): no fill of the whole lists
-__global__ __launch_bounds__(TPB) void k_pair_pad(const int* __restrict__ totals, const int* __restrict__ seg_begin, int seg,
-                                                 long long* __restrict__ in_idx, long long* __restrict__ out_idx) {
-    const int k = blockIdx.x;
-    const int cnt = totals[k];
-    const long long base = (long long)seg_begin[k] * seg;
-    const int end = (seg_begin[k + 1] - seg_begin[k]) * seg;
-    for (int i = cnt + threadIdx.x; i < end; i += TPB) { in_idx[base + i] = -1; out_idx[base + i] = -1; }
+__global__ __launch_bounds__(TPB) void k_pair_fill_multi(const PairJobs J) {
+    __shared__ int s_tile[PAIR_ROWS * PAIR_PITCH];
+    __shared__ int s_seg[512];
+    const int j = pair_job_of(J.block_begin, J.n_jobs, blockIdx.x);
+    pair_fill_body(J.nbr[j], J.n[j], J.K[j], J.table[j], nullptr, J.totals[j], J.seg_begin[j], J.seg, J.in_idx[j], J.out_idx[j],
+                   J.seg_offset[j], blockIdx.x - J.block_begin[j], s_tile, s_seg);
 }
 }  // namespace
 }  // namespace pbn
+
+// pbn_rulebook_pairs_multi: pbn_rulebook_pair_counts + pbn_rulebook_pair_fill_dev of up to 16 maps in three launches
+extern "C" int pbn_rulebook_pairs_multi(const pbn_pair_job* jobs, int n_jobs, int segment, pbn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!jobs || n_jobs < 1 || n_jobs > PAIR_MAX_JOBS || segment < 1) return PBN_ERR_ARG;
+    PairJobs J;
+    J.n_jobs = n_jobs; J.seg = segment;
+    int blocks = 0, cols = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const pbn_pair_job& q = jobs[j];
+        if (q.n < 0 || q.n_offsets < 1 || q.n_offsets > 512 || !q.nbr || !q.table || !q.totals || !q.seg_begin || !q.in_idx ||
+            !q.out_idx || !q.seg_offset)
+            return PBN_ERR_ARG;
+        J.nbr[j] = q.nbr; J.table[j] = q.table; J.totals[j] = q.totals; J.seg_begin[j] = q.seg_begin;
+        J.in_idx[j] = (long long*)q.in_idx; J.out_idx[j] = (long long*)q.out_idx; J.seg_offset[j] = (long long*)q.seg_offset;
+        J.n[j] = q.n; J.K[j] = q.n_offsets;
+        J.block_begin[j] = blocks; J.col_begin[j] = cols;
+        blocks += q.n > 0 ? (q.n + PAIR_ROWS - 1) / PAIR_ROWS : 1;      // an empty map keeps one (empty) block: it publishes seg_begin
+        cols += q.n_offsets;
+    }
+    for (int j = n_jobs; j <= PAIR_MAX_JOBS; ++j) { J.block_begin[j] = blocks; J.col_begin[j] = cols; }
+    hipLaunchKernelGGL(k_pair_count_multi, dim3(blocks), dim3(TPB), 0, stream, J);
+    hipLaunchKernelGGL(k_pair_scan_multi, dim3(cols), dim3(64), 0, stream, J);
+    hipLaunchKernelGGL(k_pair_fill_multi, dim3(blocks), dim3(TPB), 0, stream, J);
+    PBN_LAUNCH_CHECK();
+    return PBN_OK;
+}
 
 extern "C" int pbn_rulebook_pair_blocks(int n) { return n > 0 ? (n + pbn::PAIR_ROWS - 1) / pbn::PAIR_ROWS : 0; }
 
@@ -861,8 +982,9 @@ extern "C" int pbn_rulebook_pair_fill(const int32_t* nbr, int n, int n_offsets, 
     { const int frc_ = fill_bytes(seg_offset, 0, sizeof(int64_t) * (size_t)n_segments, stream); if (frc_ != PBN_OK) return frc_; }
     if (n == 0) return PBN_OK;
     if (!nbr || !table || !seg_start) return PBN_ERR_ARG;
+    if (n_offsets > 512) return PBN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_pair_fill, dim3(pbn_rulebook_pair_blocks(n)), dim3(TPB), 0, stream, nbr, n, n_offsets, table, seg_start,
-                       seg, (long long*)in_idx, (long long*)out_idx, (long long*)seg_offset);
+                       (const int*)nullptr, (int*)nullptr, seg, (long long*)in_idx, (long long*)out_idx, (long long*)seg_offset);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
@@ -872,14 +994,12 @@ extern "C" int pbn_rulebook_pair_fill_dev(const int32_t* nbr, int n, int n_offse
                                           pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0 || n_offsets < 1 || seg < 1 || !totals || !seg_begin) return PBN_ERR_ARG;
-    hipLaunchKernelGGL(k_pair_segments, dim3(1), dim3(64), 0, stream, totals, n_offsets, seg, seg_begin);
-    if (n > 0) {
-        if (!nbr || !table || !in_idx || !out_idx || !seg_offset) return PBN_ERR_ARG;
-        hipLaunchKernelGGL(k_pair_fill, dim3(pbn_rulebook_pair_blocks(n)), dim3(TPB), 0, stream, nbr, n, n_offsets, table, seg_begin,
-                           seg, (long long*)in_idx, (long long*)out_idx, (long long*)seg_offset);
-        hipLaunchKernelGGL(k_pair_pad, dim3(n_offsets), dim3(TPB), 0, stream, totals, seg_begin, seg, (long long*)in_idx,
-                           (long long*)out_idx);
-    }
+    if (n_offsets > 512) return PBN_ERR_UNSUPPORTED;
+    if (!nbr || !table || !in_idx || !out_idx || !seg_offset) return PBN_ERR_ARG;
+    // n == 0: one (empty) block still publishes seg_begin.  The tails of the last segments are NOT padded: the consumer
+    // bounds every offset by its pair count (pbn_spconv_wgrad's pair_counts = `totals`)
+    hipLaunchKernelGGL(k_pair_fill, dim3(n > 0 ? pbn_rulebook_pair_blocks(n) : 1), dim3(TPB), 0, stream, nbr, n, n_offsets, table,
+                       (const int*)nullptr, totals, seg_begin, seg, (long long*)in_idx, (long long*)out_idx, (long long*)seg_offset);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }

@@ -242,6 +242,17 @@ def _pair_array(pyr, plan):
     if hit is None:
         arr = (N.PairLists * 14)()
         keep = []
+        maps = {}
+        for slot in plan.pair_slots:
+            if slot < 5:
+                maps[slot] = pyr.kernel_map(1 << slot, 3)
+            elif slot == 5:
+                maps[slot] = pyr.kernel_map(1, 5)
+            elif slot < 10:
+                maps[slot] = pyr.down_map(1 << (slot - 6))
+            else:
+                maps[slot] = pyr.up_map(2 << (slot - 10))
+        C.rulebook_pairs_dev_multi([maps[sl] for sl in plan.pair_slots])       # all lists of the lineage in three launches
         for slot in plan.pair_slots:
             if slot < 5:
                 nbr = pyr.kernel_map(1 << slot, 3)
