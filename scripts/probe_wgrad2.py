@@ -34,7 +34,8 @@ for level, cin, cout in ((4, 256, 256), (3, 256, 256), (3, 128, 128), (2, 128, 1
     pairs = int((nbr >= 0).sum())
     line = "L%d %3d->%3d rows %6d pairs %7d:" % (level, cin, cout, n, pairs)
     for w in WGS:
-        os.environ["PBN_WGRAD_WGS"] = str(w)
+        os.environ["PBN_WGRAD_WGS"] = str(abs(w))
+        os.environ["PBN_WGRAD_MAXT"] = os.environ.get("MAXT", "4")
         cells = []
         for dbg in DBGS:
             os.environ["PBN_WGRAD_DBG"] = str(dbg)
