@@ -315,23 +315,8 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
 }
 
 
-// ---- 16-bit slabs, round 3: the same contraction with the gathers on the LDS-DMA path ------------------------------
-// k_wgrad16 keeps ONE step in flight: every step is two dependent memory latencies (pair indices, then rows) behind a
-// barrier -- 3.5-5 us per step of 32 pairs against ~0.2 us of gather / LDS / MFMA work (scripts/probe_wgrad.py: stride-8
-// 256->256, 13 steps per workgroup, 72 us).  k_wgrad_dma is the same tiling (2 x 2 waves, WA x WB tiles each, 32 pairs per
-// step, transpose reads) with a ring of WD_RING steps:
-//   * rows go global -> LDS with buffer_load_dwordx4 ... lds (no staging registers): instruction j of a step fills the
-//     j-th KiB of the slot = 64 consecutive 16-byte chunks of the [32 pairs][tile channels] image, WD_DEPTH steps ahead;
-//   * the pair indices of step t travel the same way 2 x WD_DEPTH steps ahead into an 8-entry index ring (512 B per step:
-//     eight lanes of every wave), so the gathers of step t read their row numbers from LDS;
-//   * one wait + one barrier per step: vmcnt((WD_DEPTH - 1) x loads per step) = "my pieces of this step have landed"
-//     (loads complete in issue order), the barrier publishes everybody's pieces and frees the slot of the previous step;
-//   * rows are dense in LDS (the DMA writes lane l at +16 l), so the 32-byte channel ranges of a row are XOR-swizzled
-//     with the row number -- applied to the GLOBAL address by the loading lane and to the LDS address by the reading
-//     lane -- so that the 8 rows a half-wave transposes per LDS cycle fall into 8 distinct 8-bank ranges.
-#define PBN_LDS_ADDR(p) ((unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)(p)))
-constexpr int WD_DEPTH = 3, WD_RING = WD_DEPTH + 1, WD_IDX_RING = 8;
-// debug build only (-DPBN_WGRAD_TIMING, scripts/wgrad_stamps.py): s_memtime of wave 0 of workgroup 0 at 6 points of its first 32 steps
+// debug build only (-DPBN_WGRAD_TIMING, make -C pbnet_amd/csrc timing; scripts/wgrad_stamps.py): s_memtime of wave 0 of workgroup 0
+// at 6 points of its first 32 steps
 #ifdef PBN_WGRAD_TIMING
 __device__ unsigned long long g_wgrad_stamp[32 * 6];
 #define PBN_WSTAMP(ST, I) { if (blockIdx.x == 0 && wave == 0 && (ST) < 32) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_wgrad_stamp[(ST) * 6 + (I)] = t_; } }
@@ -339,205 +324,15 @@ __device__ unsigned long long g_wgrad_stamp[32 * 6];
 #define PBN_WSTAMP(ST, I)
 #endif
 
-template <int TILES> __device__ __forceinline__ int wd_swz(int r) {
-    if constexpr (TILES == 8) return r & 7;
-    else if constexpr (TILES == 4) return (r >> 1) & 3;
-    else if constexpr (TILES == 2 || TILES == 6) return (r >> 2) & 1;   // 6: rows r and r + 4 share their 8-bank base
-    else return 0;                                                      // odd tile counts: the pitch itself spreads the rows
-}
-__host__ __device__ constexpr int wd_slot_bytes(int wa, int wb) { return ((2 * wa + 2 * wb + 3) / 4) * 4096; }
-__host__ __device__ constexpr int wd_lds_bytes(int wa, int wb) { return WD_RING * wd_slot_bytes(wa, wb) + WD_IDX_RING * 512; }
-
-template <typename T, int WA, int WB, bool IDENT>
-__global__ __launch_bounds__(256) void k_wgrad_dma(const WgradArgs a) {
-    constexpr int CIT = 2 * WA, COT = 2 * WB;               // 16-channel tiles per workgroup
-    constexpr int WXB = CIT * 32, WGB = COT * 32;           // bytes per row of the two images
-    constexpr int NI = CIT + COT;                           // gather instructions (1 KiB of LDS each) per step
-    constexpr int NIW = (NI + 3) / 4;                       // ... per wave (the tail beyond NI: dummies, same counts in every wave)
-    constexpr int NL = NIW + (IDENT ? 0 : 1);               // vector-memory loads per wave and step
-    constexpr int SLOT = wd_slot_bytes(WA, WB);
-    constexpr int D = WD_DEPTH, R = WD_RING;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    unsigned char* const s_idx = smem + R * SLOT;           // [WD_IDX_RING][in_idx 32 x int64 | out_idx 32 x int64]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 15, kg = lane >> 4;
-    const WgradTile wt = wgrad_tile(a.strips, a.K, a.splits);
-    if (!wt.live) return;
-    const int k = wt.k;
-    const int cib = wt.strip / a.co_groups, cob = wt.strip % a.co_groups;
-    const int ci_base = cib * (CIT * 16), co_base = cob * (COT * 16);
-    const int wa = wave >> 1, wb = wave & 1;
-
-    long long p_lo, p_hi;
-    if (a.seg_begin) { p_lo = (long long)a.seg_begin[k] * a.segment; p_hi = a.counts ? p_lo + a.counts[k] : (long long)a.seg_begin[k + 1] * a.segment; }
-    else { p_lo = 0; p_hi = a.n_pairs; }
-    const long long len = p_hi - p_lo;
-    const long long per_split = ((len + a.splits - 1) / a.splits + W16_SP - 1) & ~(long long)(W16_SP - 1);
-    const long long s_lo = min(p_lo + per_split * wt.split, p_hi), s_hi = min(s_lo + per_split, p_hi);
-    const int rem = (int)(s_hi - s_lo);                     // pairs of this workgroup
-    const int steps = (a.dbg & 1) ? 0 : (rem + W16_SP - 1) / W16_SP;
-    // The workgroups of one split walk pair lists that name the SAME rows in the same (ascending) order: started together
-    // they would all pull the same few cache lines through one L2 channel at any moment (measured: stride-16 256->256, 108
-    // workgroups, 14 us per step).  Each workgroup therefore starts at its own point of the range and wraps around: issue
-    // step t works on block (t + rot) % steps -- a fixed function of the workgroup, so the summation order stays fixed.
-    const int rot = (a.dbg & 4) ? 0 : (int)(((long long)(k * a.strips + wt.strip) * steps) / (a.K * a.strips));
-    auto block_of = [&](int t) { const int b = t + rot; return t >= steps ? -1 : (b >= steps ? b - steps : b); };
-
-    constexpr unsigned NOREC = 0xfffffff0u, OOB = 0xfffffff8u;
-    const auto rsrc = [](const void* p) {
-        const unsigned long long v = (unsigned long long)(uintptr_t)p;
-        return i32x4{(int)(unsigned)v, (int)(unsigned)(v >> 32), (int)NOREC, 0x00020000};
-    };
-    const i32x4 rs_x = rsrc(a.x), rs_g = rsrc(a.g);
-    const unsigned ldx_b = (unsigned)a.ld_x * 2u, ldg_b = (unsigned)a.ld_g * 2u;
-    const int cin8 = (a.cin + 7) & ~7, cout8 = (a.cout + 7) & ~7;
-
-    // this lane's chunk of each of the wave's instructions: row of the step, byte offset inside the slab row (the channel
-    // range the swizzle assigns to this LDS position), row pitch
-    int g_row[NIW];
-    unsigned g_col[NIW], g_ld[NIW];
-    bool g_ok[NIW];
-#pragma unroll
-    for (int e = 0; e < NIW; ++e) {
-        const int j = wave + 4 * e;
-        const bool isx = j < CIT;
-        const int q = (isx ? j : j - CIT) * 64 + lane;
-        const int per = isx ? 2 * CIT : 2 * COT;
-        const int row = q / per, c16 = q - row * per;
-        const int m = (c16 >> 1) ^ (isx ? wd_swz<CIT>(row) : wd_swz<COT>(row));
-        const int ch = (isx ? ci_base : co_base) + m * 16 + (c16 & 1) * 8;
-        g_row[e] = row;
-        g_ok[e] = j < NI && ch < (isx ? cin8 : cout8);
-        g_col[e] = (unsigned)ch * 2u;
-        g_ld[e] = isx ? ldx_b : ldg_b;
-    }
-    const unsigned lds_base = PBN_LDS_ADDR(smem), lds_idx = PBN_LDS_ADDR(s_idx);
-    // pair indices of step t -> index ring: lanes 8 w .. 8 w + 7 of wave w carry chunk c = lane (pairs 2 (c & 15), +1 of the
-    // input list for c < 16, of the output list for c >= 16)
-    const i32x4 rs_i = rsrc(wave < 2 ? (const void*)a.in_idx : (const void*)a.out_idx);
-    const bool idx_lane = (lane >> 3) == wave;
-    auto idx_dma = [&](int t) {
-        if constexpr (!IDENT) {
-            const int blk = block_of(t);
-            const int p0 = blk * W16_SP + (lane & 15) * 2;
-            const unsigned off = (blk >= 0 && p0 < rem && !(a.dbg & 32)) ? (unsigned)(s_lo + p0) * 8u : OOB;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_idx + (unsigned)(t & (WD_IDX_RING - 1)) * 512u);
-            if (idx_lane) {
-                unsigned keep_;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                             "buffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep_) : "s"(dst), "v"(off), "s"(rs_i) : "memory");
-            }
-        }
-    };
-    // rows of step t -> slot t % R
-    auto gather = [&](int t, unsigned slot) {
-        const unsigned char* ring = s_idx + (t & (WD_IDX_RING - 1)) * 512;
-        const int blk = block_of(t);
-        int id[NIW];
-#pragma unroll
-        for (int e = 0; e < NIW; ++e) {       // all the row numbers first: one LDS latency per step, not one per instruction
-            const bool isx = wave + 4 * e < CIT;
-            if constexpr (IDENT) id[e] = (int)s_lo + blk * W16_SP + g_row[e];
-            else id[e] = *reinterpret_cast<const volatile int*>(ring + (isx ? 0 : 256) + g_row[e] * 8);
-        }
-#pragma unroll
-        for (int e = 0; e < NIW; ++e) {
-            const int j = wave + 4 * e;
-            const bool isx = j < CIT;
-            const int pr = blk * W16_SP + g_row[e];
-            const unsigned off = (g_ok[e] && blk >= 0 && pr < rem && id[e] >= 0 && !(a.dbg & 8)) ? (unsigned)id[e] * g_ld[e] + g_col[e] : OOB;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * (unsigned)SLOT + (unsigned)j * 1024u);
-            const i32x4 rs = isx ? rs_x : rs_g;
-            unsigned keep_;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                         "buffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep_) : "s"(dst), "v"(off), "s"(rs) : "memory");
-        }
-    };
-
-    f32x4 acc[WA][WB];
-#pragma unroll
-    for (int ta = 0; ta < WA; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < WB; ++tb) acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (steps > 0) {
-        // prologue: the loop's issue pattern (indices of step t + 2 D, then rows of step t + D) for t = -D .. -1, so that the
-        // loop's wait count holds from its first step; the indices of steps 0 .. D - 1 go first and are published alone
-#pragma unroll
-        for (int j = 0; j < D; ++j) idx_dma(j);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" : : : "memory");
-#pragma unroll
-        for (int j = 0; j < D; ++j) { idx_dma(j + D); gather(j, (unsigned)j); }
-        // per-lane LDS byte offsets of the transpose reads: row 4 kg + (i >> 2) (and + 16), 8 bytes at (i & 3) of the range
-        const int r_lo = kg * 4 + (i >> 2);
-        int rd_x[WA], rd_g[WB];
-#pragma unroll
-        for (int ta = 0; ta < WA; ++ta) rd_x[ta] = r_lo * WXB + (((wa * WA + ta) ^ wd_swz<CIT>(r_lo)) * 32) + (i & 3) * 8;
-#pragma unroll
-        for (int tb = 0; tb < WB; ++tb)
-            rd_g[tb] = CIT * 1024 + r_lo * WGB + (((wb * WB + tb) ^ wd_swz<COT>(r_lo)) * 32) + (i & 3) * 8;
-        unsigned slot = 0;
-        for (int st = 0; st < steps; ++st) {
-            PBN_WSTAMP(st, 0);
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"((D - 1) * NL) : "memory");
-            PBN_WSTAMP(st, 1);
-            asm volatile("s_barrier" : : : "memory");
-            PBN_WSTAMP(st, 2);
-            const unsigned char* cur = smem + slot * SLOT;
-            const unsigned refill = slot == 0 ? R - 1 : slot - 1;     // slot of step st - 1 = slot of step st + D
-            slot = slot == R - 1 ? 0 : slot + 1;
-            idx_dma(st + 2 * D);
-            PBN_WSTAMP(st, 3);
-            gather(st + D, refill);
-            PBN_WSTAMP(st, 4);
-            if (a.dbg & 16) continue;
-            u32x4 fa[WA], fb[WB];
-#pragma unroll
-            for (int ta = 0; ta < WA; ++ta) {
-                const unsigned char* src = cur + rd_x[ta];
-                const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(src));
-                const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(src + 16 * WXB));
-                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-                fa[ta] = u32x4{l2.x, l2.y, h2.x, h2.y};
-            }
-#pragma unroll
-            for (int tb = 0; tb < WB; ++tb) {
-                const unsigned char* src = cur + rd_g[tb];
-                const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(src));
-                const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(src + 16 * WGB));
-                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-                fb[tb] = u32x4{l2.x, l2.y, h2.x, h2.y};
-            }
-#pragma unroll
-            for (int ta = 0; ta < WA; ++ta)
-#pragma unroll
-                for (int tb = 0; tb < WB; ++tb) mfma_step<T>(fa[ta], fb[tb], acc[ta][tb]);
-            PBN_WSTAMP(st, 5);
-        }
-        // the DMA writes issued for the steps past the end still target this workgroup's LDS
-        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-    }
-    if (a.dbg & 2) return;
-    // D layout: column = lane & 15 (co), row = kg * 4 + r (ci)
-    float* out = a.out + ((size_t)wt.split * a.K + k) * (size_t)a.cin * a.cout;
-#pragma unroll
-    for (int ta = 0; ta < WA; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < WB; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ci = ci_base + (wa * WA + ta) * 16 + kg * 4 + r, co = co_base + (wb * WB + tb) * 16 + i;
-                if (ci < a.cin && co < a.cout) out[(size_t)ci * a.cout + co] = acc[ta][tb][r];
-            }
-}
-
-
-// ---- k_wgrad_ring: k_wgrad16's tiling and LDS images behind a register ring of WR_DEPTH steps -----------------------
-// (The LDS-DMA form above is kept for the record: its gathers never stall -- cycle stamps, scripts/wgrad_stamps.py -- but
-// one `buffer_load_dwordx4 ... lds` takes ~700 cycles to ISSUE with 64 active lanes, ~3000 cycles per step of 16 KiB.)
+// ---- k_wgrad_ring (round 3): k_wgrad16's tiling and LDS images behind a register ring of WR_DEPTH steps --------------
+// k_wgrad16 keeps ONE step in flight: every step is two dependent memory latencies (pair indices, then rows) behind a
+// barrier.  (Tried first and measured out: the gathers on the LDS-DMA path, `buffer_load_dwordx4 ... lds` with per-lane
+// addresses into a swizzled dense image.  Its loads never stalled -- cycle stamps -- but one such instruction takes ~700
+// cycles to ISSUE with 64 active lanes, ~3000 cycles per 16 KiB step; the register ring below spends 1500.)
+// Workgroups of one split walk pair lists that name the SAME rows in the same ascending order: started together they pull
+// the same few cache lines through one L2 channel at any moment (measured with the DMA form on the stride-16 level: 14 us
+// per step), so every workgroup starts at its own point of its range and wraps around (`rot`): a fixed function of the
+// workgroup, hence a fixed summation order.
 // A thread owns row tid / 8 of the step and up to four 16-byte chunks of it (chunks c8, c8 + 8 of either image), so it
 // needs two pair indices per step.  Issue order per step t: indices of step t + 2 D - 1, rows of step t + D (addresses from
 // the indices of step t + D, loaded at step t + 1 - D); at the top of step s the rows of step s + 1 are waited for with
@@ -574,7 +369,7 @@ __global__ __launch_bounds__(256) void k_wgrad_ring(const WgradArgs a) {
     const int rem = (int)(s_hi - s_lo);
     const int steps = (a.dbg & 1) ? 0 : (rem + W16_SP - 1) / W16_SP;
     const int steps_pad = (steps + D - 1) / D * D;          // the loop is unrolled over the register stages
-    // staggered start (see k_wgrad_dma): issue step t works on block (t + rot) % steps
+    // staggered start (see above): issue step t works on block (t + rot) % steps
     const int rot = (a.dbg & 4) ? 0 : (int)(((long long)(k * a.strips + wt.strip) * steps) / (a.K * a.strips));
     auto block_of = [&](int t) { const int b = t + rot; return t >= steps ? -1 : (b >= steps ? b - steps : b); };
 
@@ -764,39 +559,6 @@ void launch_ring(const WgradArgs& a, int wa, int wb, dim3 grid, hipStream_t stre
     }
 }
 
-template <typename T, int WA, int WB>
-int launch_dma_c(const WgradArgs& a, dim3 grid, hipStream_t stream) {
-    const size_t lds = (size_t)wd_lds_bytes(WA, WB);
-    if (a.in_idx) {
-        auto kern = k_wgrad_dma<T, WA, WB, false>;
-        if (lds > 64 * 1024) PBN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
-    } else {
-        auto kern = k_wgrad_dma<T, WA, WB, true>;
-        if (lds > 64 * 1024) PBN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
-    }
-    return PBN_OK;
-}
-template <typename T, int WA>
-int launch_dma_b(const WgradArgs& a, int wb, dim3 grid, hipStream_t stream) {
-    switch (wb) {
-        case 1: return launch_dma_c<T, WA, 1>(a, grid, stream);
-        case 2: return launch_dma_c<T, WA, 2>(a, grid, stream);
-        case 3: return launch_dma_c<T, WA, 3>(a, grid, stream);
-        default: return launch_dma_c<T, WA, 4>(a, grid, stream);
-    }
-}
-template <typename T>
-int launch_dma(const WgradArgs& a, int wa, int wb, dim3 grid, hipStream_t stream) {
-    switch (wa) {
-        case 1: return launch_dma_b<T, 1>(a, wb, grid, stream);
-        case 2: return launch_dma_b<T, 2>(a, wb, grid, stream);
-        case 3: return launch_dma_b<T, 3>(a, wb, grid, stream);
-        default: return launch_dma_b<T, 4>(a, wb, grid, stream);
-    }
-}
-
 template <typename T, int WA>
 void launch16_b(const WgradArgs& a, int wb, dim3 grid, hipStream_t stream) {
     switch (wb) {
@@ -862,13 +624,12 @@ extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g
     a.counts = seg_begin ? pair_counts : nullptr;
     a.dbg = getenv("PBN_WGRAD_DBG") ? atoi(getenv("PBN_WGRAD_DBG")) : 0;   // measurement only: 1 = no main loop, 2 = no stores
     a.ld_x = ld_x; a.ld_g = ld_g; a.cin = cin; a.cout = cout; a.K = n_offsets; a.segment = segment; a.n_pairs = n_pairs_total;
-    // 16-bit slabs whose rows can be read in 16-byte chunks take the bf16/f16 matrix-core forms: k_wgrad_dma (default) or
+    // 16-bit slabs whose rows can be read in 16-byte chunks take the bf16/f16 matrix-core forms: k_wgrad_ring (default) or
     // k_wgrad16 (PBN_WGRAD_FORM=16, the round-2 kernel, kept as the cross-check); PBN_WGRAD_FORM=32: always the f32-MFMA form
     static const int form_env = getenv("PBN_WGRAD_FORM") ? atoi(getenv("PBN_WGRAD_FORM")) : 0;
     const bool form16 = form_env != 32 && dtype != PBN_F32 && (ld_x % 8) == 0 && (ld_g % 8) == 0 &&
                         ld_x >= ((cin + 7) & ~7) && ld_g >= ((cout + 7) & ~7) && (((uintptr_t)x | (uintptr_t)g) & 15) == 0;
-    const bool ring = form16 && form_env != 16 && form_env != 17;     // 17: the LDS-DMA form (kept for the record)
-    const bool dma = form16 && form_env == 17;
+    const bool ring = form16 && form_env != 16;
     int wa = 0, wb = 0, strips;
     bool small_level = false;
     if (form16) {
@@ -877,7 +638,7 @@ extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g
         wb = cot >= 7 ? 4 : (cot + 1) / 2;
         // few pairs per offset (the stride-8/16 levels): quarter tiles instead of pair splits -- 4x the workgroups with no
         // partial slabs and no reduce launch (measured, stride-16 256->256: 23 -> 13 us; stride-8: 35 us either way)
-        small_level = (ring || dma) && n_pairs_total / n_offsets < 3000 && cdiv(cit, 2 * wa) * cdiv(cot, 2 * wb) * n_offsets < 256;
+        small_level = ring && n_pairs_total / n_offsets < 3000 && cdiv(cit, 2 * wa) * cdiv(cot, 2 * wb) * n_offsets < 256;
         const int maxt = getenv("PBN_WGRAD_MAXT") ? atoi(getenv("PBN_WGRAD_MAXT")) : (small_level ? 2 : 4);
         if (wa > maxt) wa = maxt;
         if (wb > maxt) wb = maxt;
@@ -888,17 +649,17 @@ extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g
         strips = cdiv(cin, 16) * a.co_groups;
     }
     // pair splits: enough workgroups for the chip, enough pairs per workgroup to amortise its prologue, bounded by the
-    // workspace.  k_wgrad_dma: ~1024 workgroups of >= 256 pairs (8 steps); the one-step-in-flight kernels: ~2048 of >= 512
+    // workspace.  k_wgrad_ring: ~1024 workgroups of >= 256 pairs (8 steps); the one-step-in-flight kernels: ~2048 of >= 512
     const int want_wgs = getenv("PBN_WGRAD_WGS") ? atoi(getenv("PBN_WGRAD_WGS")) : 0;
     const int min_pairs_env = getenv("PBN_WGRAD_MIN_PAIRS") ? atoi(getenv("PBN_WGRAD_MIN_PAIRS")) : 0;
-    const long long target = want_wgs > 0 ? want_wgs : ((dma || ring) ? 1024 : 2048);
-    const long long min_pairs = min_pairs_env > 0 ? min_pairs_env : ((dma || ring) ? 256 : 512);
+    const long long target = want_wgs > 0 ? want_wgs : (ring ? 1024 : 2048);
+    const long long min_pairs = min_pairs_env > 0 ? min_pairs_env : (ring ? 256 : 512);
     const long long pairs_per_offset = n_pairs_total / n_offsets + 1;
     long long splits = target / ((long long)strips * n_offsets) + 1;
     if (splits > pairs_per_offset / min_pairs + 1) splits = pairs_per_offset / min_pairs + 1;
     // every split writes and re-reads a dW-sized partial: at most ~32 MB of partials (256->256 cubes: 4 splits)
     const long long by_traffic = (32LL << 20) / (long long)(sizeof(float) * (size_t)n_out) + 1;
-    if ((ring || dma) && splits > by_traffic) splits = by_traffic;
+    if (ring && splits > by_traffic) splits = by_traffic;
     if (small_level && want_wgs <= 0) splits = 1;
     const long long by_ws = workspace ? (long long)(workspace_bytes / (sizeof(float) * (size_t)n_out)) : 1;
     if (splits > by_ws) splits = by_ws;
@@ -911,10 +672,6 @@ extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g
     if (ring) {
         if (dtype == PBN_BF16) launch_ring<__hip_bfloat16>(a, wa, wb, grid, stream);
         else launch_ring<__half>(a, wa, wb, grid, stream);
-    } else if (dma) {
-        const int rc = dtype == PBN_BF16 ? launch_dma<__hip_bfloat16>(a, wa, wb, grid, stream)
-                                         : launch_dma<__half>(a, wa, wb, grid, stream);
-        if (rc != PBN_OK) return rc;
     } else if (form16) {
         if (dtype == PBN_BF16) launch16<__hip_bfloat16>(a, wa, wb, grid, stream);
         else launch16<__half>(a, wa, wb, grid, stream);

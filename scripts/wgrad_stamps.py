@@ -1,4 +1,4 @@
-"""Cycle stamps of k_wgrad_dma's main loop (debug library built with -DPBN_WGRAD_TIMING, PBNET_HIP_LIB=pbnet_amd/libpbnet_hip_wgt.so):
+"""Cycle stamps of k_wgrad_ring's main loop (debug library: make -C pbnet_amd/csrc timing, PBNET_HIP_LIB=pbnet_amd/libpbnet_hip_timing.so):
 wave 0 of workgroup 0, first 32 steps; columns = 100 MHz ticks between the stamps (wait, barrier, index DMA, gathers, compute)."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

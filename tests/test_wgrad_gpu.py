@@ -1,4 +1,4 @@
-"""GPU tier: pbn_spconv_wgrad (csrc/wgrad.hip) on its own -- the LDS-DMA kernel (default) against the round-2 kernels
+"""GPU tier: pbn_spconv_wgrad (csrc/wgrad.hip) on its own -- the register-ring kernel (default) against the round-2 kernel
 (PBN_WGRAD_FORM is read once per process, so the cross-check runs in a child process) and against a float64 contraction of
 the same pair lists: every tile shape of the MinkUNet layers, channel tails, identity pairs (1x1 / linear), empty offsets,
 pair ranges that are not a multiple of the step, strided slab views (a skip slab's columns)."""
@@ -96,7 +96,7 @@ def test_wgrad_against_float64(dtype):
             assert float(got[3].abs().max()) == 0.0          # an offset without pairs: exact zeros
 
 
-def test_wgrad_dma_matches_round2_kernel():
+def test_wgrad_ring_matches_round2_kernel():
     """The same lists through k_wgrad16 (PBN_WGRAD_FORM=16) in a child process: same tiles, same pair order inside a
     workgroup -> the two kernels differ only by where the pair range is split."""
     code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
