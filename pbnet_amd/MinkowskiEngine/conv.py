@@ -89,6 +89,7 @@ class _BatchPacker(object):
 
     def refresh(self, device, dtype, with_dgrad):
         with self.lock:
+            stream_raw = torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch._C._cuda_getDevice())
             jobs = []
             for m in list(_PACK_MODULES):
                 w = m.kernel
@@ -104,7 +105,10 @@ class _BatchPacker(object):
                     k3 = w if w.dim() == 3 else w.unsqueeze(0)
                     k, a, b = int(k3.shape[0]), int(k3.shape[1]), int(k3.shape[2])
                     cin, cout, vpo, cin_p, cout_p, n_steps = _pack_dims(k, a, b, dtype, transpose)
-                    old = None if hit is None else hit[1][0]
+                    # repack IN PLACE only what no other stream has fetched since it was packed: a convolution of another
+                    # scene in flight may still be reading it (such readers were recorded on the buffer, see _PackCache:
+                    # dropping it here is then safe, the allocator holds it back until their work has drained)
+                    old = None if (hit is None or hit[2] != stream_raw or hit[3]) else hit[1][0]
                     shape = (n_steps, cout_p // 16, 64, _ELEMS[dtype])
                     out = old if (old is not None and tuple(old.shape) == shape and old.dtype == dtype) else \
                         torch.empty(*shape, dtype=dtype, device=device)
@@ -122,17 +126,31 @@ class _BatchPacker(object):
                 max_vec = max(j[4][11] * (j[4][10] // 16) * 64 for j in jobs)
                 cached = (sig, table, max_vec)
                 self.tables[(device, dtype)] = cached
+            cached[1].record_stream(torch.cuda.current_stream(device))     # the table may have been built on another stream
             N.check(N.lib().pbn_pack_weights_batch(N.c_vp(cached[1].data_ptr()), len(jobs), int(cached[2]), _DT[dtype],
                                                    N.current_stream()), "pbn_pack_weights_batch")
             for m, form, key, packed, _ in jobs:
-                m._cache.store[(form, dtype)] = (key, packed)
+                m._cache.store[(form, dtype)] = (key, packed, stream_raw, set())
 
 
 _BATCH = _BatchPacker()
 
 
 class _PackCache(object):
-    """Per-module cache of packed weights keyed by (form, dtype) -> (parameter version key, packed)."""
+    """Per-module cache of packed weights keyed by (form, dtype) -> (parameter version key, packed, raw stream of the pack
+    launch, raw streams other than that one that have fetched the buffer).  A fetch from another stream is recorded on the
+    buffer (Tensor.record_stream), so that a later repack or release cannot hand its memory out while that stream's
+    convolutions still read it."""
+
+    @staticmethod
+    def _note_stream(hit):
+        w = hit[1][0]
+        if w.is_cuda:
+            raw = torch._C._cuda_getCurrentRawStream(w.device.index)
+            if raw != hit[2] and raw not in hit[3]:
+                w.record_stream(torch.cuda.current_stream(w.device))
+                hit[3].add(raw)
+        return hit[1]
 
     def __init__(self, owner=None):
         self.store = {}
@@ -142,17 +160,23 @@ class _PackCache(object):
         key = (dtype, kernel._version, kernel.data_ptr(), kernel.device)
         hit = self.store.get((form, dtype))
         if hit is not None and hit[0] == key:
-            return hit[1]
+            return self._note_stream(hit)
         owner = None if self.owner is None else self.owner()
         if owner is not None and kernel.is_cuda and kernel.data_ptr() == owner.kernel.data_ptr():
             _BATCH.refresh(kernel.device, dtype, torch.is_grad_enabled() or form == "d")
             hit = self.store.get((form, dtype))
             if hit is not None and hit[0] == key:
-                return hit[1]
+                return self._note_stream(hit)
         k3 = kernel if kernel.dim() == 3 else kernel.unsqueeze(0)
-        hit = (key, pack_weight(k3.detach(), dtype, flip=flip, transpose=transpose))
+        hit = self._entry(key, pack_weight(k3.detach(), dtype, flip=flip, transpose=transpose))
         self.store[(form, dtype)] = hit
         return hit[1]
+
+    @staticmethod
+    def _entry(key, packed):
+        w = packed[0]
+        raw = torch._C._cuda_getCurrentRawStream(w.device.index) if w.is_cuda else 0
+        return (key, packed, raw, set())
 
     def get(self, kernel, dtype):
         return self._lookup("f", kernel, dtype, False, False)
@@ -166,9 +190,10 @@ class _PackCache(object):
         key = (dtype, weight._version, weight.data_ptr(), weight.device)
         hit = self.store.get(("l", dtype))
         if hit is None or hit[0] != key:
-            hit = (key, pack_weight(weight.detach().unsqueeze(0), dtype, transpose=True))
+            hit = self._entry(key, pack_weight(weight.detach().unsqueeze(0), dtype, transpose=True))
             self.store[("l", dtype)] = hit
-        return hit[1]
+            return hit[1]
+        return self._note_stream(hit)
 
 
 SPLITK_WORKSPACE_BYTES = 256 << 20

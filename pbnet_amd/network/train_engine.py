@@ -189,13 +189,13 @@ class TrainPlan(object):
             cache, kernel = conv._cache, conv.kernel
             ver = kernel._version
             hit = cache.store.get(("f", dt))
-            pk = hit[1] if (hit is not None and hit[0][1] == ver) else cache.get(kernel, dt)
+            pk = cache._note_stream(hit) if (hit is not None and hit[0][1] == ver) else cache.get(kernel, dt)
             if pk[0] is not self.packed[2 * i]:
                 self.packed[2 * i] = pk[0]
                 ops[i].w, ops[i].vpo, ops[i].n_steps, ops[i].cout_p = pk[0].data_ptr(), pk[1], pk[2], pk[3]
             if ops[i].want_dx:
                 hit = cache.store.get(("d", dt))
-                pk = hit[1] if (hit is not None and hit[0][1] == ver) else cache.get_dgrad(kernel, dt, conv._dgrad_flip)
+                pk = cache._note_stream(hit) if (hit is not None and hit[0][1] == ver) else cache.get_dgrad(kernel, dt, conv._dgrad_flip)
                 if pk[0] is not self.packed[2 * i + 1]:
                     self.packed[2 * i + 1] = pk[0]
                     ops[i].w_d, ops[i].vpo_d, ops[i].n_steps_d, ops[i].cout_p_d = pk[0].data_ptr(), pk[1], pk[2], pk[3]
