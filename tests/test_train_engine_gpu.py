@@ -135,3 +135,28 @@ def test_engine_eval_and_no_grad_fall_back():
     with torch.no_grad():
         net(ME.SparseTensor(feats, torch.from_numpy(coords).to(DEV)))
     assert not net.__dict__.get("_train_plans")
+
+
+@pytest.mark.parametrize("n_points", [40, 700])
+def test_engine_on_tiny_scenes(n_points):
+    """A handful of voxels: the coarse levels hold one to a few rows (batch-norm statistics over one row, weight-gradient
+    workgroups without a single pair, quarter tiles): fp32, bit-identical to the module path."""
+    g = torch.Generator().manual_seed(n_points)
+    xyz = torch.randint(0, 24 if n_points < 100 else 40, (n_points, 3), generator=g, dtype=torch.int32)
+    coords = torch.unique(torch.cat([torch.zeros(n_points, 1, dtype=torch.int32), xyz], 1), dim=0).numpy()
+    torch.manual_seed(3)
+    net = Mink_unet(6, 32, arch="MinkUNet14A").to(DEV).train()
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    feats = torch.randn(len(coords), 6, device=DEV)
+    target = torch.randn(len(coords), 32, device=DEV)
+    try:
+        ref = _step(net, feats, coords, target, False, True)
+        net.load_state_dict(state)
+        got = _step(net, feats, coords, target, True, True)
+        assert net.__dict__.get("_train_plans"), "the executor did not run"
+    finally:
+        TE.ENABLED, TE.SORTED = True, False
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    for k in ref[2]:
+        assert torch.equal(got[2][k], ref[2][k]), k
+        assert torch.isfinite(got[2][k]).all(), k
