@@ -88,6 +88,15 @@ class GradientReducer(object):
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._next = 0                          # next bucket index to go on the wire
         self._hooks = []
+        # which parameters received a gradient is HOST knowledge (p.grad is None or not): the ranks exchange it over a host-side
+        # (gloo) group -- round 2 sent it through the device and read it back, one pipeline drain per step.  Collective: every
+        # rank constructs its reducer at the same point (as it must for the buckets to match).
+        self._host_group = None
+        if self.world > 1 and dist.get_backend() != "gloo":
+            try:
+                self._host_group = dist.new_group(backend="gloo")
+            except Exception:                   # no gloo in this build: the device path below
+                self._host_group = None
         if overlap and self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -128,7 +137,9 @@ class GradientReducer(object):
         if self.world == 1:
             return 0
         dev = next((p.grad.device for p in self.params if p.grad is not None), self.params[0].device)
-        used = torch.tensor([1 if p.grad is not None else 0 for p in self.params], dtype=torch.int32, device=dev)
+        on_host = self._host_group is not None or dist.get_backend() == "gloo"
+        used = torch.tensor([1 if p.grad is not None else 0 for p in self.params], dtype=torch.int32,
+                            device="cpu" if on_host else dev)
         for b in self.buckets[self._next:]:
             flat = self._flat(b, self.params[0] if dev is None else torch.empty(0, device=dev))
             for pi, p in enumerate(b["params"]):
@@ -140,10 +151,10 @@ class GradientReducer(object):
                 else:
                     sl.zero_()
             b["work"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-        used_work = dist.all_reduce(used, op=dist.ReduceOp.MAX, async_op=True)
+        used_work = dist.all_reduce(used, op=dist.ReduceOp.MAX, async_op=True, group=self._host_group)
         self._next = 0
         used_work.wait()
-        used_h = used.cpu().tolist()
+        used_h = used.tolist()                   # a device tensor (no host group) is read back here: one synchronisation
         for b in self.buckets:
             b["work"].wait()
             flat = b["flat"]
