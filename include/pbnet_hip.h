@@ -268,12 +268,12 @@ int pbn_bn_act_train_backward(const void* x, int ld_x, const void* dy, int ld_dy
  *   pbn_rulebook_pair_counts : table int32[pbn_rulebook_pair_blocks(n), K] (per-block prefix counts, kept for the fill)
  *                              and totals int32[K] (pairs per offset) -- the caller reads the totals back, gives every
  *                              offset ceil(total/seg) segments of `seg` pairs and passes their first-segment indices
- *   pbn_rulebook_pair_fill   : in_idx / out_idx int64[n_segments * seg] (-1 = padding), seg_offset int64[n_segments]
+ *   pbn_rulebook_pair_fill   : in_idx / out_idx int32[n_segments * seg] (-1 = padding; int64 until round 3), seg_offset int64[n_segments]
  * Pairs of an offset keep ascending output-row order; positions are prefix counts (no atomics): deterministic. */
 int pbn_rulebook_pair_blocks(int n);
 int pbn_rulebook_pair_counts(const int32_t* nbr, int n, int n_offsets, int32_t* table, int32_t* totals, pbn_stream_t stream);
 int pbn_rulebook_pair_fill(const int32_t* nbr, int n, int n_offsets, const int32_t* table, const int32_t* seg_start, int seg,
-                           int n_segments, int64_t* in_idx, int64_t* out_idx, int64_t* seg_offset, pbn_stream_t stream);
+                           int n_segments, int32_t* in_idx, int32_t* out_idx, int64_t* seg_offset, pbn_stream_t stream);
 
 /* pbn_rulebook_pair_fill_dev -- the same lists with NO host knowledge of the pair counts (no read-back between
  * pbn_rulebook_pair_counts and the fill: a training step builds ~40 maps): seg_begin int32[n_offsets + 1] is computed on the
@@ -282,7 +282,7 @@ int pbn_rulebook_pair_fill(const int32_t* nbr, int n, int n_offsets, const int32
  * is NOT padded: the consumer bounds every offset by its pair count (pbn_spconv_wgrad: pair_counts = `totals`).  One launch
  * (every block derives seg_begin from the totals itself); n_offsets <= 512. */
 int pbn_rulebook_pair_fill_dev(const int32_t* nbr, int n, int n_offsets, const int32_t* table, const int32_t* totals,
-                               int segment, int32_t* seg_begin, int64_t* in_idx, int64_t* out_idx, int64_t* seg_offset,
+                               int segment, int32_t* seg_begin, int32_t* in_idx, int32_t* out_idx, int64_t* seg_offset,
                                pbn_stream_t stream);
 
 /* pbn_rulebook_pairs_multi -- counts + device-side fill (the two calls above) of up to 16 maps in THREE launches: the
@@ -294,8 +294,8 @@ typedef struct {
     int32_t* table;
     int32_t* totals;
     int32_t* seg_begin;
-    int64_t* in_idx;
-    int64_t* out_idx;
+    int32_t* in_idx;
+    int32_t* out_idx;
     int64_t* seg_offset;
 } pbn_pair_job;
 int pbn_rulebook_pairs_multi(const pbn_pair_job* jobs, int n_jobs, int segment, pbn_stream_t stream);
@@ -308,8 +308,8 @@ int pbn_rulebook_pairs_multi(const pbn_pair_job* jobs, int n_jobs, int segment, 
  * its offset's last segment as well (a stride-16 level holds ~450 pairs per offset in segments of 4096); all lists NULL = identity pairs (1x1 convolution / linear layer; n_offsets 1, n_pairs_total rows).  x [*, ld_x], g [*, ld_g] of `dtype` (widened exactly), dw f32[K, cin, cout], any cin / cout.
  * fp32 accumulation in a fixed order (deterministic).  workspace: pbn_spconv_wgrad_workspace_bytes (pair splits). */
 size_t pbn_spconv_wgrad_workspace_bytes(int n_offsets, int cin, int cout);
-int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g, int dtype, const int64_t* in_idx,
-                     const int64_t* out_idx, const int32_t* seg_begin, const int32_t* pair_counts, int segment,
+int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g, int dtype, const int32_t* in_idx,
+                     const int32_t* out_idx, const int32_t* seg_begin, const int32_t* pair_counts, int segment,
                      int n_pairs_total, int n_offsets, int cin, int cout, float* dw, void* workspace, size_t workspace_bytes,
                      pbn_stream_t stream);
 
@@ -573,8 +573,8 @@ typedef struct {
 } pbn_train_op;
 
 typedef struct {
-    const int64_t* in_idx;
-    const int64_t* out_idx;
+    const int32_t* in_idx;
+    const int32_t* out_idx;
     const int32_t* seg_begin;
     const int32_t* counts;
     int32_t segment, n_pairs_estimate;

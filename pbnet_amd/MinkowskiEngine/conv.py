@@ -260,7 +260,7 @@ def _gather_rows(src, idx):
 
 def rulebook_pairs(nbr, segment=WGRAD_PAIR_SEGMENT):
     """The map as offset-major lists of (input row, output row) pairs cut into segments of `segment` pairs, -1 padded:
-    (in_idx, out_idx) int64 [segments * segment], seg_offset int64 [segments], segments.  One read-back (pairs per
+    (in_idx, out_idx) int32 [segments * segment], seg_offset int64 [segments], segments.  One read-back (pairs per
     offset) sizes the lists.  Cached on the map tensor: every layer of a level shares its map."""
     hit = getattr(nbr, "_pbn_pairs", None)
     if hit is not None and hit[4] == segment:
@@ -279,8 +279,8 @@ def rulebook_pairs(nbr, segment=WGRAD_PAIR_SEGMENT):
     seg_begin = np.concatenate([[0], np.cumsum(segs)]).astype(np.int32)        # [K+1]
     seg_start = seg_begin[:-1]
     n_seg = int(segs.sum())
-    in_idx = torch.empty(n_seg * segment, dtype=torch.int64, device=dev)
-    out_idx = torch.empty(n_seg * segment, dtype=torch.int64, device=dev)
+    in_idx = torch.empty(n_seg * segment, dtype=torch.int32, device=dev)
+    out_idx = torch.empty(n_seg * segment, dtype=torch.int32, device=dev)
     seg_offset = torch.empty(n_seg, dtype=torch.int64, device=dev)
     seg_begin_d = torch.from_numpy(seg_begin).to(dev)
     N.check(lib.pbn_rulebook_pair_fill(N.ptr(nbr), v, k, N.ptr(table), N.ptr(seg_begin_d), segment,
@@ -311,8 +311,8 @@ def rulebook_pairs_dev(nbr, segment=WGRAD_PAIR_SEGMENT):
     st = N.current_stream()
     N.check(lib.pbn_rulebook_pair_counts(N.ptr(nbr), v, k, N.ptr(table), N.ptr(totals), st), "pbn_rulebook_pair_counts")
     cap = (v * k) // segment + k
-    in_idx = torch.empty(cap * segment, dtype=torch.int64, device=dev)
-    out_idx = torch.empty(cap * segment, dtype=torch.int64, device=dev)
+    in_idx = torch.empty(cap * segment, dtype=torch.int32, device=dev)
+    out_idx = torch.empty(cap * segment, dtype=torch.int32, device=dev)
     seg_offset = torch.empty(cap, dtype=torch.int64, device=dev)
     seg_begin = torch.empty(k + 1, dtype=torch.int32, device=dev)
     N.check(lib.pbn_rulebook_pair_fill_dev(N.ptr(nbr), v, k, N.ptr(table), N.ptr(totals), segment, N.ptr(seg_begin),
@@ -342,8 +342,8 @@ def rulebook_pairs_dev_multi(maps, segment=WGRAD_PAIR_SEGMENT):
             table = torch.empty(max(lib.pbn_rulebook_pair_blocks(v), 1) * k, dtype=torch.int32, device=dev)
             totals = torch.empty(k, dtype=torch.int32, device=dev)
             cap = (v * k) // segment + k
-            in_idx = torch.empty(cap * segment, dtype=torch.int64, device=dev)
-            out_idx = torch.empty(cap * segment, dtype=torch.int64, device=dev)
+            in_idx = torch.empty(cap * segment, dtype=torch.int32, device=dev)
+            out_idx = torch.empty(cap * segment, dtype=torch.int32, device=dev)
             seg_offset = torch.empty(cap, dtype=torch.int64, device=dev)
             seg_begin = torch.empty(k + 1, dtype=torch.int32, device=dev)
             q = jobs[j]

@@ -797,8 +797,8 @@ __global__ __launch_bounds__(64) void k_pair_scan(int* __restrict__ table, int n
 // K <= a few hundred) and block 0 publishes them as seg_begin_out[K + 1] -- no separate launch, no read-back
 __device__ __forceinline__ void pair_fill_body(const int* __restrict__ nbr, int n, int K, const int* __restrict__ table,
                                                const int* __restrict__ seg_start, const int* __restrict__ totals,
-                                               int* __restrict__ seg_begin_out, int seg, long long* __restrict__ in_idx,
-                                               long long* __restrict__ out_idx, long long* __restrict__ seg_offset, int blk,
+                                               int* __restrict__ seg_begin_out, int seg, int* __restrict__ in_idx,
+                                               int* __restrict__ out_idx, long long* __restrict__ seg_offset, int blk,
                                                int* s_tile, int* s_seg) {
     const int row0 = blk * PAIR_ROWS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -850,8 +850,8 @@ __device__ __forceinline__ void pair_fill_body(const int* __restrict__ nbr, int 
 
 __global__ __launch_bounds__(TPB) void k_pair_fill(const int* __restrict__ nbr, int n, int K, const int* __restrict__ table,
                                                   const int* __restrict__ seg_start, const int* __restrict__ totals,
-                                                  int* __restrict__ seg_begin_out, int seg, long long* __restrict__ in_idx,
-                                                  long long* __restrict__ out_idx, long long* __restrict__ seg_offset) {
+                                                  int* __restrict__ seg_begin_out, int seg, int* __restrict__ in_idx,
+                                                  int* __restrict__ out_idx, long long* __restrict__ seg_offset) {
     __shared__ int s_tile[PAIR_ROWS * PAIR_PITCH];
     __shared__ int s_seg[512];
     pair_fill_body(nbr, n, K, table, seg_start, totals, seg_begin_out, seg, in_idx, out_idx, seg_offset, blockIdx.x, s_tile, s_seg);
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(TPB) void k_pair_fill(const int* __restrict__ nbr, 
 constexpr int PAIR_MAX_JOBS = 16;
 struct PairJobs {
     const int* nbr[PAIR_MAX_JOBS]; int* table[PAIR_MAX_JOBS]; int* totals[PAIR_MAX_JOBS]; int* seg_begin[PAIR_MAX_JOBS];
-    long long* in_idx[PAIR_MAX_JOBS]; long long* out_idx[PAIR_MAX_JOBS]; long long* seg_offset[PAIR_MAX_JOBS];
+    int* in_idx[PAIR_MAX_JOBS]; int* out_idx[PAIR_MAX_JOBS]; long long* seg_offset[PAIR_MAX_JOBS];
     int n[PAIR_MAX_JOBS], K[PAIR_MAX_JOBS];
     int block_begin[PAIR_MAX_JOBS + 1];      // row blocks (count / fill)
     int col_begin[PAIR_MAX_JOBS + 1];        // columns (scan)
@@ -939,7 +939,7 @@ extern "C" int pbn_rulebook_pairs_multi(const pbn_pair_job* jobs, int n_jobs, in
             !q.out_idx || !q.seg_offset)
             return PBN_ERR_ARG;
         J.nbr[j] = q.nbr; J.table[j] = q.table; J.totals[j] = q.totals; J.seg_begin[j] = q.seg_begin;
-        J.in_idx[j] = (long long*)q.in_idx; J.out_idx[j] = (long long*)q.out_idx; J.seg_offset[j] = (long long*)q.seg_offset;
+        J.in_idx[j] = q.in_idx; J.out_idx[j] = q.out_idx; J.seg_offset[j] = (long long*)q.seg_offset;
         J.n[j] = q.n; J.K[j] = q.n_offsets;
         J.block_begin[j] = blocks; J.col_begin[j] = cols;
         blocks += q.n > 0 ? (q.n + PAIR_ROWS - 1) / PAIR_ROWS : 1;      // an empty map keeps one (empty) block: it publishes seg_begin
@@ -970,27 +970,27 @@ extern "C" int pbn_rulebook_pair_counts(const int32_t* nbr, int n, int n_offsets
 }
 
 extern "C" int pbn_rulebook_pair_fill(const int32_t* nbr, int n, int n_offsets, const int32_t* table, const int32_t* seg_start,
-                                      int seg, int n_segments, int64_t* in_idx, int64_t* out_idx, int64_t* seg_offset,
+                                      int seg, int n_segments, int32_t* in_idx, int32_t* out_idx, int64_t* seg_offset,
                                       pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0 || n_offsets < 1 || seg < 1 || n_segments < 0) return PBN_ERR_ARG;
     if (n_segments == 0) return PBN_OK;
     if (!in_idx || !out_idx || !seg_offset) return PBN_ERR_ARG;
     // padding slots (and surplus segments) read as -1 / offset 0
-    { const int frc_ = fill_bytes(in_idx, 0xff, sizeof(int64_t) * (size_t)n_segments * seg, stream); if (frc_ != PBN_OK) return frc_; }
-    { const int frc_ = fill_bytes(out_idx, 0xff, sizeof(int64_t) * (size_t)n_segments * seg, stream); if (frc_ != PBN_OK) return frc_; }
+    { const int frc_ = fill_bytes(in_idx, 0xff, sizeof(int32_t) * (size_t)n_segments * seg, stream); if (frc_ != PBN_OK) return frc_; }
+    { const int frc_ = fill_bytes(out_idx, 0xff, sizeof(int32_t) * (size_t)n_segments * seg, stream); if (frc_ != PBN_OK) return frc_; }
     { const int frc_ = fill_bytes(seg_offset, 0, sizeof(int64_t) * (size_t)n_segments, stream); if (frc_ != PBN_OK) return frc_; }
     if (n == 0) return PBN_OK;
     if (!nbr || !table || !seg_start) return PBN_ERR_ARG;
     if (n_offsets > 512) return PBN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_pair_fill, dim3(pbn_rulebook_pair_blocks(n)), dim3(TPB), 0, stream, nbr, n, n_offsets, table, seg_start,
-                       (const int*)nullptr, (int*)nullptr, seg, (long long*)in_idx, (long long*)out_idx, (long long*)seg_offset);
+                       (const int*)nullptr, (int*)nullptr, seg, in_idx, out_idx, (long long*)seg_offset);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
 
 extern "C" int pbn_rulebook_pair_fill_dev(const int32_t* nbr, int n, int n_offsets, const int32_t* table, const int32_t* totals,
-                                          int seg, int32_t* seg_begin, int64_t* in_idx, int64_t* out_idx, int64_t* seg_offset,
+                                          int seg, int32_t* seg_begin, int32_t* in_idx, int32_t* out_idx, int64_t* seg_offset,
                                           pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0 || n_offsets < 1 || seg < 1 || !totals || !seg_begin) return PBN_ERR_ARG;
@@ -999,7 +999,7 @@ extern "C" int pbn_rulebook_pair_fill_dev(const int32_t* nbr, int n, int n_offse
     // n == 0: one (empty) block still publishes seg_begin.  The tails of the last segments are NOT padded: the consumer
     // bounds every offset by its pair count (pbn_spconv_wgrad's pair_counts = `totals`)
     hipLaunchKernelGGL(k_pair_fill, dim3(n > 0 ? pbn_rulebook_pair_blocks(n) : 1), dim3(TPB), 0, stream, nbr, n, n_offsets, table,
-                       (const int*)nullptr, totals, seg_begin, seg, (long long*)in_idx, (long long*)out_idx, (long long*)seg_offset);
+                       (const int*)nullptr, totals, seg_begin, seg, in_idx, out_idx, (long long*)seg_offset);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }

@@ -60,7 +60,7 @@ __host__ inline long long wgrad_grid(int strips, int K, int splits) {
 
 struct WgradArgs {
     const void* x; const void* g;
-    const long long* in_idx; const long long* out_idx;   // pair lists (nullptr: identity, pair p = row p)
+    const int* in_idx; const int* out_idx;               // pair lists (nullptr: identity, pair p = row p)
     const int* seg_begin;                                 // [K+1] first segment of every offset (nullptr: one offset, n_pairs pairs)
     const int* counts;                                    // [K] pairs of every offset (nullptr: whole segments, -1 padded)
     float* out;                                           // dW [K, cin, cout] (splits == 1) or partial [splits, K, cin, cout]
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
     auto load_idx = [&](long long p, int& ri, int& ro) {
         ri = -1; ro = -1;
         if (p < w_hi) {
-            if (a.in_idx) { ri = (int)a.in_idx[p]; ro = (int)a.out_idx[p]; }
+            if (a.in_idx) { ri = a.in_idx[p]; ro = a.out_idx[p]; }
             else { ri = (int)p; ro = (int)p; }
         }
     };
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
         for (int e = 0; e < NPT; ++e) {
             const long long p = s_lo + (long long)step * W16_SP + c_row[e];
             idx[e] = -1;
-            if (p < s_hi && c_ok[e]) idx[e] = a.in_idx ? (int)(c_isx[e] ? a.in_idx[p] : a.out_idx[p]) : (int)p;
+            if (p < s_hi && c_ok[e]) idx[e] = a.in_idx ? (c_isx[e] ? a.in_idx[p] : a.out_idx[p]) : (int)p;
         }
     };
     auto gather = [&](const int (&idx)[NPT], u32x4 (&v)[NPT]) {
@@ -402,12 +402,12 @@ __global__ __launch_bounds__(256) void k_wgrad_ring(const WgradArgs a) {
 #pragma unroll
         for (int e = 0; e < NPT; ++e) stg[d][e] = u32x4{0u, 0u, 0u, 0u};
     }
-    // pair indices of step t -> idr[t % D] (low dwords of the two int64 entries)
+    // pair indices of step t -> idr[t % D]
     auto issue_idx = [&](int t, unsigned (&dst)[2]) {
         if constexpr (!IDENT) {
             const int blk = block_of(t);
             const int pr = blk * W16_SP + row;
-            const unsigned off = (blk >= 0 && pr < rem) ? (unsigned)(s_lo + pr) * 8u : OOB;
+            const unsigned off = (blk >= 0 && pr < rem) ? (unsigned)(s_lo + pr) * 4u : OOB;
             asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(dst[0]) : "v"(off), "s"(rs_ii));
             asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(dst[1]) : "v"(off), "s"(rs_io));
         }
@@ -604,8 +604,8 @@ extern "C" size_t pbn_spconv_wgrad_workspace_bytes(int n_offsets, int cin, int c
     return (size_t)64 * n_offsets * cin * cout * sizeof(float);   // up to 64 pair splits
 }
 
-extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g, int dtype, const int64_t* in_idx,
-                                const int64_t* out_idx, const int32_t* seg_begin, const int32_t* pair_counts, int segment, int n_pairs_total,
+extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g, int dtype, const int32_t* in_idx,
+                                const int32_t* out_idx, const int32_t* seg_begin, const int32_t* pair_counts, int segment, int n_pairs_total,
                                 int n_offsets, int cin, int cout, float* dw, void* workspace, size_t workspace_bytes,
                                 pbn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -620,7 +620,7 @@ extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g
     }
     if (!x || !g) return PBN_ERR_ARG;
     WgradArgs a;
-    a.x = x; a.g = g; a.in_idx = (const long long*)in_idx; a.out_idx = (const long long*)out_idx; a.seg_begin = seg_begin;
+    a.x = x; a.g = g; a.in_idx = in_idx; a.out_idx = out_idx; a.seg_begin = seg_begin;
     a.counts = seg_begin ? pair_counts : nullptr;
     a.dbg = getenv("PBN_WGRAD_DBG") ? atoi(getenv("PBN_WGRAD_DBG")) : 0;   // measurement only: 1 = no main loop, 2 = no stores
     a.ld_x = ld_x; a.ld_g = ld_g; a.cin = cin; a.cout = cout; a.K = n_offsets; a.segment = segment; a.n_pairs = n_pairs_total;

@@ -206,7 +206,8 @@ def test_rulebook_pairs_against_nonzero():
         want_in = nbr.cpu()[kv[:, 1], kv[:, 0]].long()
         valid = (in_idx >= 0).cpu()
         assert torch.equal(valid, (out_idx >= 0).cpu()) and int(valid.sum()) == kv.shape[0]
-        assert torch.equal(in_idx.cpu()[valid], want_in) and torch.equal(out_idx.cpu()[valid], kv[:, 1])
+        assert in_idx.dtype == torch.int32 and out_idx.dtype == torch.int32
+        assert torch.equal(in_idx.cpu()[valid].long(), want_in) and torch.equal(out_idx.cpu()[valid].long(), kv[:, 1])
         seg_of_slot = torch.arange(n_seg * seg) // seg
         assert torch.equal(seg_offset.cpu()[seg_of_slot[valid]], kv[:, 0])
         # padding only at the tail of an offset's last segment
