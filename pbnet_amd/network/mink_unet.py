@@ -222,6 +222,7 @@ class MinkUNet(nn.Module):
         self.__dict__.pop("_state_tensors", None)
         self.__dict__.pop("_train_plans", None)
         self.__dict__.pop("_train_engine_ok", None)
+        self.__dict__.pop("_train_engine_norms", None)
         self._plans.clear()
 
     def _apply(self, fn, *args, **kwargs):

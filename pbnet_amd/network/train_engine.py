@@ -219,7 +219,12 @@ def usable(net, x):
         net.__dict__["_train_engine_ok"] = bool(ok)
     if not ok:
         return False
-    return all(m.bn.training for m in (net.bn0, net.bntr7))     # .train() / .eval() reach every submodule alike
+    norms = net.__dict__.get("_train_engine_norms")
+    if norms is None:
+        from ..MinkowskiEngine import MinkowskiBatchNorm
+        norms = [m.bn for name, m in net.named_modules() if isinstance(m, MinkowskiBatchNorm)]
+        net.__dict__["_train_engine_norms"] = norms
+    return all(bn.training for bn in norms)                     # a frozen (eval-mode) batch norm anywhere: the module path
 
 
 def _plan(net, dtype, want_input_grad):
@@ -254,14 +259,7 @@ def _pair_array(pyr, plan):
                 maps[slot] = pyr.up_map(2 << (slot - 10))
         C.rulebook_pairs_dev_multi([maps[sl] for sl in plan.pair_slots])       # all lists of the lineage in three launches
         for slot in plan.pair_slots:
-            if slot < 5:
-                nbr = pyr.kernel_map(1 << slot, 3)
-            elif slot == 5:
-                nbr = pyr.kernel_map(1, 5)
-            elif slot < 10:
-                nbr = pyr.down_map(1 << (slot - 6))
-            else:
-                nbr = pyr.up_map(2 << (slot - 10))
+            nbr = maps[slot]
             in_idx, out_idx, seg_begin, counts = C.rulebook_pairs_dev(nbr)
             k = int(nbr.shape[1])
             p = arr[slot]

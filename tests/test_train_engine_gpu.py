@@ -135,6 +135,13 @@ def test_engine_eval_and_no_grad_fall_back():
     with torch.no_grad():
         net(ME.SparseTensor(feats, torch.from_numpy(coords).to(DEV)))
     assert not net.__dict__.get("_train_plans")
+    net.block3[0].norm1.bn.eval()                        # one frozen batch norm: the executor would normalise with batch statistics
+    out = net(ME.SparseTensor(feats, torch.from_numpy(coords).to(DEV))).F
+    out.float().sum().backward()
+    assert not net.__dict__.get("_train_plans")
+    net.train()
+    net(ME.SparseTensor(feats, torch.from_numpy(coords).to(DEV))).F.float().sum().backward()
+    assert net.__dict__.get("_train_plans")
 
 
 @pytest.mark.parametrize("n_points", [40, 700])
