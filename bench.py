@@ -122,6 +122,8 @@ def timed_leg(model, b, t, inflight, device, steps, warmup=None, blocks=3):
         torch.cuda.synchronize()
         bl.append(time.perf_counter() - t0)
     e = float(np.median(bl))
+    for _ in range(2):                         # this thread's stream has its own allocator pool: fill it outside the timing
+        one_step(model, b, t)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(5):
