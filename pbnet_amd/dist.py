@@ -4,6 +4,8 @@ all-reduce of /root/reference/train.py:345 (DDP), here as flat buckets sized for
 gradient hooks so that the ring overlaps backward (GradientReducer).  SyncBatchNorm (train.py:343-344) is deliberately
 not reproduced (BASELINE.json north_star: "gradients only"); sync_buffers() makes the BatchNorm statistics of all ranks
 equal before validation / checkpointing."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -92,7 +94,7 @@ class GradientReducer(object):
         # (gloo) group -- round 2 sent it through the device and read it back, one pipeline drain per step.  Collective: every
         # rank constructs its reducer at the same point (as it must for the buckets to match).
         self._host_group = None
-        if self.world > 1 and dist.get_backend() != "gloo":
+        if self.world > 1 and dist.get_backend() != "gloo" and os.environ.get("PBN_REDUCER_HOST_GROUP", "1") != "0":
             try:
                 self._host_group = dist.new_group(backend="gloo")
             except Exception:                   # no gloo in this build: the device path below
