@@ -216,6 +216,28 @@ def test_rulebook_pairs_against_nonzero():
             assert ((per_seg > 0).all()) and (valid.view(n_seg, seg).long().diff(dim=1) <= 0).all()
 
 
+def test_rulebook_pairs_multi_equals_single():
+    """pbn_rulebook_pairs_multi (all maps of a lineage in three launches) against the per-map device-side fill: the same
+    lists entry for entry (below every offset's pair count), the same segment starts and counts; an empty map among them."""
+    from pbnet_amd.MinkowskiEngine.conv import rulebook_pairs_dev, rulebook_pairs_dev_multi, WGRAD_PAIR_SEGMENT as SEG
+    g = torch.Generator().manual_seed(11)
+    shapes = [(3000, 27, 0.3), (70001, 27, 0.26), (333, 8, 0.12), (5000, 125, 0.15), (900, 8, 0.125), (257, 27, 0.0)]
+
+    def make():
+        gg = torch.Generator().manual_seed(11)
+        return [torch.where(torch.rand(v, k, generator=gg) < d, torch.randint(0, v, (v, k), generator=gg),
+                            torch.full((v, k), -1)).to(torch.int32).to(DEV) for v, k, d in shapes]
+    single = [rulebook_pairs_dev(m) for m in make()]
+    multi = rulebook_pairs_dev_multi(make())
+    for (v, k, _), a, b in zip(shapes, single, multi):
+        cnt = a[3].cpu()
+        assert torch.equal(cnt, b[3].cpu()) and torch.equal(a[2].cpu(), b[2].cpu())
+        seg_begin = a[2].cpu().long()
+        for o in range(k):
+            lo, n = int(seg_begin[o]) * SEG, int(cnt[o])
+            assert torch.equal(a[0][lo:lo + n], b[0][lo:lo + n]) and torch.equal(a[1][lo:lo + n], b[1][lo:lo + n])
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 def test_native_batch_norm_matches_torch(dtype, tol):
     """csrc/bnorm.hip (train-mode statistics, normalisation, gradients) against torch.nn.BatchNorm1d on the same slab:
