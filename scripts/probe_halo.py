@@ -1,0 +1,97 @@
+"""The LDS-staged family (spconv_halo.hip) against the gather kernels on layers of the bench scene, replayed from a HIP graph:
+microseconds per launch, plus the table build.  PBN_PROBE_STREAMS=4: the same layer on four streams at once."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pbnet_amd.MinkowskiEngine as ME
+from pbnet_amd import synth
+from pbnet_amd.MinkowskiEngine.conv import spconv_forward, spconv_forward_halo, HaloTable
+dev = "cuda:0"
+batch, _, _ = synth.make_val_batch(seed=2, copies=1)
+cm = ME.CoordinateManager(torch.from_numpy(batch["xyz_voxel"]).to(dev))
+pyr = cm.sorted().pyramid
+torch.manual_seed(0)
+REP = 20
+STREAMS = int(os.environ.get("PBN_PROBE_STREAMS", "1"))
+SLOTS = [int(s) for s in os.environ.get("PBN_PROBE_SLOTS", "0").split(",")]
+DT = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[os.environ.get("PBN_PROBE_DTYPE", "bf16")]
+
+
+def timed(fn):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    if STREAMS > 1:
+        streams = [torch.cuda.Stream() for _ in range(STREAMS)]
+        graphs = []
+        for st in streams:
+            with torch.cuda.stream(st):
+                fn()
+            torch.cuda.synchronize()
+            gq = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gq, stream=st):
+                for _ in range(REP):
+                    fn()
+            graphs.append(gq)
+        def go():
+            for st, gq in zip(streams, graphs):
+                with torch.cuda.stream(st):
+                    gq.replay()
+        go(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); go(); go(); torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (2 * REP * STREAMS) * 1e6
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(REP):
+            fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); g.replay(); g.replay(); e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (2 * REP) * 1e3
+
+
+tables = {}
+
+
+def run(level, cin, cout, k=3):
+    n = pyr.n[level]
+    nbr = pyr.kernel_map(1 << level, k)
+    if (level, k) not in tables:
+        torch.cuda.synchronize()
+        HaloTable(nbr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ht = HaloTable(nbr)
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - t0) / 5 * 1e6
+        cnt = ht.counts()
+        print("  tables L%d k=%d: %d rows, halo %.2fx, largest %d, build %.1f us (incl. allocation)" % (
+            level, k, n, cnt.sum().item() / n, cnt.max().item(), tb), flush=True)
+        tables[(level, k)] = ht
+    ht = tables[(level, k)]
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=k, dimension=3).to(dev)
+    packed = conv._cache.get(conv.kernel, DT)
+    e = 16 // torch.empty(0, dtype=DT).element_size()
+    x = torch.randn(n, packed[1] * e, device=dev).to(DT)
+    out = torch.empty(n, packed[3], dtype=DT, device=dev)
+    out2 = torch.empty_like(out)
+    t_old = timed(lambda: spconv_forward(x, nbr, n, packed, out=out))
+    line = "L%d rows=%6d %3d->%3d K=%3d: gather kernels %.1f us |" % (level, n, cin, cout, k ** 3, t_old)
+    for s in SLOTS:
+        try:
+            t_new = timed(lambda: spconv_forward_halo(x, ht, packed, out=out2, lds_slots=s))
+        except RuntimeError as ex:
+            line += " halo[%d] %s" % (s, ex)
+            continue
+        err = (out.float() - out2.float()).abs().max().item()
+        line += " halo[slots %d] %.1f us (x%.2f, diff %.2e)" % (s, t_new, t_old / t_new, err)
+    print(line, flush=True)
+
+
+cases = [(0, 96, 96), (0, 128, 96), (1, 96, 96), (1, 128, 96), (1, 32, 32), (2, 64, 64), (2, 128, 128), (2, 192, 128),
+         (3, 128, 128), (3, 256, 256), (0, 32, 32, 5)]
+if len(sys.argv) > 1:
+    cases = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+for c in cases:
+    run(*c)
