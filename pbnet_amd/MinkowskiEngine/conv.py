@@ -268,7 +268,7 @@ class HaloTable(object):
         return self.view("cnt", torch.int32, self.layout.tiles)
 
 
-def spconv_forward_halo(feats, halo, packed, scale=None, shift=None, residual=None, relu=False, out=None, lds_slots=0):
+def spconv_forward_halo(feats, halo, packed, scale=None, shift=None, residual=None, relu=False, out=None, lds_slots=0, cfg=0):
     """pbn_spconv_forward_halo: the convolution over a map with halo tables (LDS-staged rows)."""
     import ctypes
     w, vpo, n_steps, cout_p = packed
@@ -283,7 +283,7 @@ def spconv_forward_halo(feats, halo, packed, scale=None, shift=None, residual=No
         N.c_vp(w.data_ptr()), vpo, n_steps, cout_p, None if scale is None else N.c_vp(scale.data_ptr()),
         None if shift is None else N.c_vp(shift.data_ptr()), None if residual is None else N.c_vp(residual.data_ptr()),
         0 if residual is None else residual.stride(0), int(bool(relu)), N.c_vp(out.data_ptr()), out.stride(0), _DT[dtype],
-        N.c_vp(halo.table.data_ptr()), ctypes.byref(halo.layout), int(lds_slots), N.current_stream())
+        N.c_vp(halo.table.data_ptr()), ctypes.byref(halo.layout), int(lds_slots), int(cfg), N.current_stream())
     N.check(rc, "pbn_spconv_forward_halo")
     return out
 

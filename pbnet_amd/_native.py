@@ -114,7 +114,7 @@ SIGNATURES = {
     "pbn_halo_build": (c_int, [ctypes.POINTER(HaloJob), c_int, c_vp]),
     "pbn_spconv_forward_halo": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_int, c_vp, c_int, c_int, c_int, c_f32p,
                                         c_f32p, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, ctypes.POINTER(HaloLayout), c_int,
-                                        c_vp]),
+                                        c_int, c_vp]),
     "pbn_spconv_wgrad_workspace_bytes": (c_size, [c_int, c_int, c_int]),
     "pbn_spconv_wgrad": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_int,
                                  c_f32p, c_vp, c_size, c_vp]),

@@ -116,6 +116,6 @@ bool wave_family_wanted(const ConvArgs& a, int dtype);
 // spconv_halo.hip: LDS-staged family over halo tables (pbn_halo_build); PBN_ERR_UNSUPPORTED when the shape is not built
 bool halo_supported(const ConvArgs& a, int tile_rows);
 int launch_halo(const ConvArgs& a, int dtype, const int* cnt, const int* rows, const unsigned short* loc,
-                const unsigned short* fmask, int tile_rows, int pitch, int lds_slots, hipStream_t stream);
+                const unsigned short* fmask, int tile_rows, int pitch, int lds_slots, int cfg, hipStream_t stream);
 
 }  // namespace pbn

@@ -136,6 +136,18 @@ __global__ __launch_bounds__(HB_TPB) void k_halo_build(const HaloJobs J) {
     }
 }
 
+// Cycle stamps (debug build only: make timing, scripts/halo_timing.py): lane 0 of every wave of the first HT_BLOCKS workgroups
+// records s_memtime at up to 48 points.
+#ifdef PBN_CONV_TIMING
+constexpr int HT_BLOCKS = 256, HT_STAMPS = 48;
+__device__ unsigned long long g_halo_timing[HT_BLOCKS * 8 * HT_STAMPS + 8];
+#define PBN_HSTAMP(I)                                                                                                 \
+    if (lane == 0 && blockIdx.x < HT_BLOCKS && blockIdx.y == 0 && (I) < HT_STAMPS)                                    \
+        g_halo_timing[((size_t)blockIdx.x * 8 + wave) * HT_STAMPS + (I)] = __builtin_readcyclecounter();
+#else
+#define PBN_HSTAMP(I)
+#endif
+
 struct HaloArgs {
     const int* cnt;
     const int* rows;
@@ -143,6 +155,7 @@ struct HaloArgs {
     const unsigned short* fmask;
     int tm, pitch;
     int hs;            // slots of the LDS row buffer (multiple of 16)
+    int csp;           // 64-byte pieces (steps) of a row staged per pass: a divisor of the steps per offset
 };
 
 #define PBN_LDS_ADDR(p) ((unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)(p)))
@@ -157,20 +170,29 @@ __device__ __forceinline__ void dma16(unsigned lds_dst, unsigned voff, const i32
                  : "memory");
 }
 
-template <typename T, int NF, int NT, int RING>
-__global__ __launch_bounds__(256) void k_spconv_halo(const ConvArgs a, const HaloArgs h) {
+// Workgroup = NW waves x 2 fragments = NW*32 output rows x NT*16 channels.  The reduction axis of a pass is the list of UNITS
+// (populated offset k, step cc of the staged pieces), offset-major; one loop iteration consumes S units: S*NT weight pieces
+// from one ring slot, S*2 row operands per wave, up to S*2*NT MFMAs per wave between two barriers.  Unit word: k | cc << 8 |
+// fragment mask << 16; 0 = padding (no fragment: nothing is issued for it).
+template <typename T, int NW, int NT, int S, int RING>
+__global__ __launch_bounds__(NW * 64) void k_spconv_halo(const ConvArgs a, const HaloArgs h) {
     static_assert(Tr<T>::ELEMS * sizeof(T) == 16, "one gather vector is 16 bytes");
-    constexpr int RW = NF * 16, TM = 4 * RW, D = RING - 1, PW = (NT + 3) / 4;
+    static_assert(RING == 2 || RING == 3, "one or two iterations of weights in flight");
+    constexpr int NF = 2, RW = NF * 16, TM = NW * RW, TPB = NW * 64, D = RING - 1;
+    constexpr int NPC = S * NT, PW = (NPC + NW - 1) / NW;                          // weight pieces per iteration / per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int K = a.K, KS = K | 1, HS = h.hs;
+    const int K = a.K, KS = K | 1, HS = h.hs, CSP = h.csp;
     const int spo = a.vpo >> 2;                                                   // 64-byte pieces (steps) per offset
-    u32x4* s_w = reinterpret_cast<u32x4*>(smem);                                  // RING x NT KiB
-    unsigned char* s_x = smem + (size_t)RING * NT * 1024;                          // (HS + 16) slots x 64 B; the last 16 stay zero
-    unsigned short* s_loc = reinterpret_cast<unsigned short*>(s_x + (size_t)(HS + 16) * 64);   // TM x KS
+    const int plane = (HS + 16) * 64;                                             // bytes of one staged piece of all slots
+    u32x4* s_w = reinterpret_cast<u32x4*>(smem);                                  // RING x NPC KiB
+    unsigned char* s_x = smem + (size_t)RING * NPC * 1024;                         // CSP planes; the last 16 slots of each stay zero
+    unsigned short* s_loc = reinterpret_cast<unsigned short*>(s_x + (size_t)CSP * plane);   // TM x KS
     int* s_rows = reinterpret_cast<int*>(s_loc + ((TM * KS + 7) & ~7));           // HS
-    int* s_grp = s_rows + HS;                                                     // K + 4 populated offsets, [K] = count
+    int* s_units = s_rows + HS;                                                   // K * CSP + 4 S (padded)
+    int* s_grp = s_units + ((K * CSP + 4 * S + 3) & ~3);                          // K + 4 populated offsets, [K] = count
     int* s_fmk = s_grp + ((K + 4 + 3) & ~3);                                      // their fragment masks
     float* s_ss = reinterpret_cast<float*>(s_fmk + ((K + 4 + 3) & ~3));           // scale | shift
+    unsigned char* s_dump = reinterpret_cast<unsigned char*>(s_ss + 2 * NT * 16);  // 1 KiB: where the DMA pieces past the end land
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,6 +203,7 @@ __global__ __launch_bounds__(256) void k_spconv_halo(const ConvArgs a, const Hal
     const int tile0 = blockIdx.y * NT;
     const int g = lane >> 4, rl = lane & 15;
     if (a.dbg & 128) return;
+    PBN_HSTAMP(0);
     const int H = h.cnt[tile];
 
     const unsigned long long in_addr = (unsigned long long)a.in, w_addr = (unsigned long long)a.w;
@@ -247,132 +270,190 @@ __global__ __launch_bounds__(256) void k_spconv_halo(const ConvArgs a, const Hal
             if (KS == K && ((TM * K) & 7) == 0) {
                 const uint4* s4 = reinterpret_cast<const uint4*>(gl);
                 uint4* d4 = reinterpret_cast<uint4*>(s_loc);
-                for (int e = tid; e < (TM * K) >> 3; e += 256) d4[e] = s4[e];
+                for (int e = tid; e < (TM * K) >> 3; e += TPB) d4[e] = s4[e];
             } else {
                 const float inv_k = 1.0f / (float)K;
-                for (int e = tid; e < TM * K; e += 256) {
+                for (int e = tid; e < TM * K; e += TPB) {
                     const int r = (int)(((float)e + 0.5f) * inv_k), k = e - r * K;
                     s_loc[r * KS + k] = gl[e];
                 }
             }
             const int h0 = H < HS ? H : HS;
-            for (int s = tid; s < h0; s += 256) s_rows[s] = h.rows[(size_t)tile * h.pitch + s];
-            if (tid < 64) reinterpret_cast<u32x4*>(s_x + (size_t)HS * 64)[tid] = u32x4{0u, 0u, 0u, 0u};
+            for (int s = tid; s < h0; s += TPB) s_rows[s] = h.rows[(size_t)tile * h.pitch + s];
+            for (int e = tid; e < CSP * 64; e += TPB)                                  // the zero slots of every plane
+                reinterpret_cast<u32x4*>(s_x + (size_t)(e >> 6) * plane + (size_t)HS * 64)[e & 63] = u32x4{0u, 0u, 0u, 0u};
         }
         __syncthreads();
+        PBN_HSTAMP(1);
         if (a.dbg & 16) return;
         const int n_pop = (a.dbg & 32) ? 0 : __builtin_amdgcn_readfirstlane(s_grp[K]);
+        const int n_u = n_pop * CSP;
+        const int n_it = (n_u + S - 1) / S;
+        {   // the unit list: offset-major, the CSP staged pieces of an offset adjacent; padded with empty units
+            const float inv_c = 1.0f / (float)CSP;
+            for (int u = tid; u < n_it * S + 3 * S; u += TPB) {
+                int v = 0;
+                if (u < n_u) {
+                    const int i = (int)(((float)u + 0.5f) * inv_c), cc = u - i * CSP;
+                    v = s_grp[i] | (cc << 8) | (s_fmk[i] << 16);
+                }
+                s_units[u] = v;
+            }
+        }
+        __syncthreads();
+        PBN_HSTAMP(2);
         const int nseg = (H + HS - 1) / HS;
-        const int npass = nseg * spo;
-        const unsigned lds_w = PBN_LDS_ADDR(s_w), lds_x = PBN_LDS_ADDR(s_x);
+        const int nchunk = spo / CSP;
+        const int npass = n_it > 0 ? nseg * nchunk : 0;
+        const unsigned lds_w = PBN_LDS_ADDR(s_w), lds_x = PBN_LDS_ADDR(s_x), lds_dump = PBN_LDS_ADDR(s_dump);
         const unsigned w_lane = (unsigned)lane * 16u;
 
-        // populated offsets and their fragment masks travel in registers: lane l of (g_lo, g_hi) holds entry l / 64 + l
-        // (offset | mask << 8); a wave-uniform index reads it with v_readlane -- no LDS round trip on the issue path
-        const int g_lo = lane < n_pop ? (s_grp[lane] | (s_fmk[lane] << 8)) : 0;
-        const int g_hi = 64 + lane < n_pop ? (s_grp[64 + lane] | (s_fmk[64 + lane] << 8)) : 0;
-        auto grp = [&](int i) -> int { return i < 64 ? __builtin_amdgcn_readlane(g_lo, i) : __builtin_amdgcn_readlane(g_hi, i - 64); };
+        // S unit words of iteration x as scalars
+        struct Units { int u[S]; };
+        auto units_at = [&](int x) -> Units {
+            const int v = s_units[x * S + (lane < S ? lane : 0)];
+            Units r;
+#pragma unroll
+            for (int s = 0; s < S; ++s) r.u[s] = __builtin_amdgcn_readlane(v, s);
+            return r;
+        };
+        const Units u_first = units_at(0), u_second = units_at(n_it > 1 ? 1 : 0);
 
-        // weights of the next group to fetch: (pass, index) in the flattened order of the loops below
-        int wp_c = 0, wp_i = 0, wp_left = n_pop > 0 ? npass : 0;
+        // weights of one iteration -> ring slot: piece pc = unit pc / NT, channel tile pc % NT; empty units and pieces past the
+        // end use an out-of-range offset (no traffic)
+        int wp_left = npass, wp_j = 0, wp_c0 = 0;              // the next iteration to fetch: passes left, index, first piece of its pass
         unsigned wp_slot = 0;
-        auto issue_w = [&]() {
-            const bool live = wp_left > 0 && !(a.dbg & 1);
-            const int k = grp(wp_i) & 0xff;
-            const unsigned gbase = ((unsigned)(k * spo + wp_c) * (unsigned)a.ntiles_total + (unsigned)tile0) * 1024u;
-            const unsigned voff = live ? w_lane : OOB;
+        auto issue_w = [&](const Units& un) {
 #pragma unroll
             for (int j = 0; j < PW; ++j) {
-                const int pc = min(wave + 4 * j, NT - 1);        // tail pieces are benign duplicates
-                dma16(__builtin_amdgcn_readfirstlane(lds_w + (wp_slot * NT + (unsigned)pc) * 1024u), voff, rs_w,
-                      __builtin_amdgcn_readfirstlane(gbase + (unsigned)pc * 1024u));
+                if (a.dbg & 256) break;
+                const int pc = wave + NW * j;
+                const int sidx = pc / NT, t = pc - sidx * NT;
+                int uw = un.u[S - 1];
+#pragma unroll
+                for (int q = S - 2; q >= 0; --q) uw = sidx == q ? un.u[q] : uw;
+                const bool live = wp_left > 0 && pc < NPC && (uw >> 16) != 0 && !(a.dbg & 1);
+                const unsigned step = (unsigned)((uw & 0xff) * spo + wp_c0 + ((uw >> 8) & 0xff));
+                const unsigned gsrc = (step * (unsigned)a.ntiles_total + (unsigned)(tile0 + t)) * 1024u;
+                // (an out-of-range piece still WRITES its 1 KiB of zeros: pieces past the end go to the dump area)
+                dma16(__builtin_amdgcn_readfirstlane(pc < NPC ? lds_w + (wp_slot * NPC + (unsigned)pc) * 1024u : lds_dump),
+                      live ? w_lane : OOB, rs_w, __builtin_amdgcn_readfirstlane(live ? gsrc : 0u));
             }
             wp_slot = wp_slot == RING - 1 ? 0 : wp_slot + 1;
-            if (++wp_i >= n_pop) {
-                wp_i = 0;
+            if (++wp_j >= n_it) {
+                wp_j = 0;
                 --wp_left;
-                if (++wp_c >= spo) wp_c = 0;
+                wp_c0 += CSP;
+                if (wp_c0 >= spo) wp_c0 = 0;
             }
         };
-        // LDS byte address of the row operand of fragment f at offset k: chunk g of the slot's 64-byte piece, chunks swizzled by
-        // slot bit 2 (conflict-free for runs of consecutive slots); none / another segment -> the zero slot
+        // LDS byte address of the row operand of fragment f for a unit: chunk g of the slot's 64-byte piece in plane cc, chunks
+        // swizzled by slot bit 2 (conflict-free for runs of consecutive slots); none / another segment -> the zero slot
         const unsigned short* my_loc = s_loc + (wave * RW + rl) * KS;
-        auto slot_addr = [&](int k, int seg0, int f) -> int {
-            int slot = (int)my_loc[f * 16 * KS + k] - seg0;
+        auto slot_addr = [&](int uw, int seg0, int f) -> int {
+            int slot = (int)my_loc[f * 16 * KS + (uw & 0xff)] - seg0;
             if ((unsigned)slot >= (unsigned)HS) slot = HS;
-            return slot * 64 + ((g ^ ((slot >> 1) & 2)) << 4);
+            return ((uw >> 8) & 0xff) * plane + slot * 64 + ((g ^ ((slot >> 1) & 2)) << 4);
         };
 
-#pragma unroll
-        for (int j = 0; j < D; ++j) issue_w();
+        if (npass > 0) {
+            issue_w(u_first);
+            if (D == 2) issue_w(wp_j == 0 ? u_first : u_second);
+        }
         unsigned slot_r = 0;
-        int seg = 0, c = 0;
+        int seg = 0, c0 = 0;
+        PBN_HSTAMP(3);
         for (int p = 0; p < npass; ++p) {
             const int seg0 = seg * HS;
             const int hseg = min(H - seg0, HS);
-            if (p > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the previous piece
-            if (c == 0 && seg > 0) {
-                for (int s = tid; s < hseg; s += 256) s_rows[s] = h.rows[(size_t)tile * h.pitch + seg0 + s];
+            if (p > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the previous pieces
+            if (c0 == 0 && seg > 0) {
+                for (int s = tid; s < hseg; s += TPB) s_rows[s] = h.rows[(size_t)tile * h.pitch + seg0 + s];
                 __syncthreads();
             }
-            if (!(a.dbg & 8)) {   // stage piece c of the segment's rows: block b = 16 slots x 64 B, lane 4 s + j' fetches chunk j' ^ swizzle(slot)
+            if (!(a.dbg & 8)) {   // stage pieces c0 .. c0+CSP-1 of the segment's rows: block = 16 slots x 64 B, lane 4 s + j' fetches chunk j' ^ swizzle(slot)
                 const int nblk = (hseg + 15) >> 4;
-                for (int b = wave; b < nblk; b += 4) {
+                for (int e = wave; e < nblk * CSP; e += NW) {
+                    const int cc = e / nblk, b = e - cc * nblk;
                     const int slot = b * 16 + (lane >> 2);
                     const int row = slot < hseg ? s_rows[slot] : -1;
-                    const unsigned voff = row >= 0 ? (unsigned)row * ld_bytes + (unsigned)c * 64u + (unsigned)((((lane & 3) ^ ((slot >> 1) & 2))) << 4) : OOB;
-                    dma16(__builtin_amdgcn_readfirstlane(lds_x + (unsigned)b * 1024u), voff, rs_in, 0u);
+                    const unsigned voff = row >= 0 ? (unsigned)row * ld_bytes + (unsigned)(c0 + cc) * 64u + (unsigned)((((lane & 3) ^ ((slot >> 1) & 2))) << 4) : OOB;
+                    dma16(__builtin_amdgcn_readfirstlane(lds_x + (unsigned)cc * (unsigned)plane + (unsigned)b * 1024u), voff, rs_in, 0u);
                 }
             }
+            if (p == 0) { PBN_HSTAMP(4); }
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (n_pop > 0) {
-                // software pipeline over the populated offsets: the row operands of offset i+1 and the slots of offset i+2 are
-                // fetched under the MFMAs of offset i -- the only LDS round trip in front of an MFMA is its own weight fragment
-                u32x4 bc[NF], bn[NF];
-                int an[NF];                                       // operand addresses of offset i+1
-                int gi = grp(0), gn = grp(n_pop > 1 ? 1 : 0);
+            if (p == 0) { PBN_HSTAMP(5); }
+            // software pipeline over the iterations of the pass: the row operands of iteration j+1 and the slots of iteration
+            // j+2 are fetched under the MFMAs of iteration j
+            Units uc = u_first, un = u_second, u2 = units_at(n_it > 2 ? 2 : n_it - 1);
+            u32x4 bc[S][NF], bn[S][NF];
+            int an[S][NF];
+#pragma unroll
+            for (int s = 0; s < S; ++s)
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
-                    bc[f] = *reinterpret_cast<const u32x4*>(s_x + slot_addr(gi & 0xff, seg0, f));
-                    an[f] = slot_addr(gn & 0xff, seg0, f);
+                    bc[s][f] = *reinterpret_cast<const u32x4*>(s_x + slot_addr(uc.u[s], seg0, f));
+                    an[s][f] = slot_addr(un.u[s], seg0, f);
                 }
-                for (int i = 0; i < n_pop; ++i) {
-                    // the weights of this group have landed (loads complete in issue order: the D-1 groups behind it may still
-                    // be in flight), and every wave has left the previous group: its ring slot is free
-                    if (!(a.dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((D - 1) * PW) : "memory");
-                    issue_w();
-                    const unsigned fm = (unsigned)gi >> 8;
-                    const u32x4* cur = s_w + slot_r * (NT * 64) + lane;
-                    slot_r = slot_r == RING - 1 ? 0 : slot_r + 1;
-                    const bool act = ((fm >> (wave * NF)) & ((1u << NF) - 1u)) != 0 && !(a.dbg & 2);
-                    u32x4 wf[NT];
-                    if (act) {
+            int vnext = s_units[(n_it > 3 ? 3 : n_it - 1) * S + (lane < S ? lane : 0)];       // units of iteration 3
+            if (p == 0) { PBN_HSTAMP(6); }
+            for (int j = 0; j < n_it; ++j) {
+                if (p == 0) { PBN_HSTAMP(8 + 4 * j); }
+                // the weights of this iteration have landed (loads complete in issue order: the D-1 iterations behind it may
+                // still be in flight), and every wave has left the previous iteration: its ring slot is free
+                if (!(a.dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((D - 1) * PW) : "memory");
+                if (p == 0) { PBN_HSTAMP(9 + 4 * j); }
+                {   // fetch the weights D iterations ahead (it may belong to the next pass: the list is the same)
+                    const int jd = j + D;
+                    if (jd < n_it) issue_w(D == 1 ? un : u2);
+                    else issue_w(jd - n_it == 0 || n_it == 1 ? u_first : u_second);
+                }
+                if (p == 0) { PBN_HSTAMP(10 + 4 * j); }
+                const u32x4* cur = s_w + slot_r * (NPC * 64) + lane;
+                slot_r = slot_r == RING - 1 ? 0 : slot_r + 1;
+                // row operands of the next iteration, slots of the one after
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) wf[t] = cur[t * 64];
-                    }
-                    const int g2 = grp(i + 2 < n_pop ? i + 2 : n_pop - 1);
+                for (int s = 0; s < S; ++s)
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) bn[f] = *reinterpret_cast<const u32x4*>(s_x + an[f]);
+                    for (int f = 0; f < NF; ++f) bn[s][f] = *reinterpret_cast<const u32x4*>(s_x + ((a.dbg & 512) ? 0 : an[s][f]));
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) an[f] = slot_addr(g2 & 0xff, seg0, f);
-                    if (act) {
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) an[s][f] = slot_addr(u2.u[s], seg0, f);
+                Units u3;
+#pragma unroll
+                for (int s = 0; s < S; ++s) u3.u[s] = __builtin_amdgcn_readlane(vnext, s);
+                vnext = s_units[(j + 4 < n_it ? j + 4 : n_it - 1) * S + (lane < S ? lane : 0)];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const unsigned fm = ((unsigned)uc.u[s] >> 16) >> (wave * NF);
+                    if ((fm & ((1u << NF) - 1u)) && !(a.dbg & 2)) {
+                        u32x4 wf[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) wf[t] = cur[(s * NT + t) * 64];
 #pragma unroll
                         for (int f = 0; f < NF; ++f) {
-                            if ((fm >> (wave * NF + f)) & 1u) {
+                            if ((fm >> f) & 1u) {
 #pragma unroll
-                                for (int t = 0; t < NT; ++t) mfma_step<T>(wf[t], bc[f], acc[f][t]);
+                                for (int t = 0; t < NT; ++t) mfma_step<T>(wf[t], bc[s][f], acc[f][t]);
                             }
                         }
                     }
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) bc[f] = bn[f];
-                    gi = gn;
-                    gn = g2;
                 }
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) bc[s][f] = bn[s][f];
+                uc = un; un = u2; u2 = u3;
+                if (p == 0) { PBN_HSTAMP(11 + 4 * j); }
             }
-            if (++c >= spo) { c = 0; ++seg; }
+            if (p == 0) { PBN_HSTAMP(7); }
+            c0 += CSP;
+            if (c0 >= spo) { c0 = 0; ++seg; }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (dummy) weight fetches
+        PBN_HSTAMP(44);
     }
 
     // ---- epilogue: lane holds channels c0..c0+3 of output row (wave*RW + f*16 + rl) ----
@@ -402,73 +483,99 @@ __global__ __launch_bounds__(256) void k_spconv_halo(const ConvArgs a, const Hal
             store4<T>(out + (size_t)p * a.ld_out + c0, v);
         }
     }
+    PBN_HSTAMP(45);
 }
 
-template <typename T, int NF, int NT, int RING>
+template <typename T, int NW, int NT, int S, int RING>
 int launch_halo_cfg(const ConvArgs& a, const HaloArgs& h, hipStream_t stream) {
-    constexpr int TM = 64 * NF;
+    constexpr int TM = 32 * NW;
     if (h.tm != TM || a.ntiles_total % NT) return PBN_ERR_UNSUPPORTED;
     const int KS = a.K | 1;
     const size_t kw = (size_t)((a.K + 4 + 3) & ~3);
-    const size_t lds = (size_t)RING * NT * 1024 + (size_t)(h.hs + 16) * 64 + sizeof(unsigned short) * (size_t)((TM * KS + 7) & ~7) +
-                       sizeof(int) * ((size_t)h.hs + 2 * kw) + sizeof(float) * 2 * NT * 16;
+    const size_t lds = (size_t)RING * S * NT * 1024 + (size_t)h.csp * (h.hs + 16) * 64 +
+                       sizeof(unsigned short) * (size_t)((TM * KS + 7) & ~7) +
+                       sizeof(int) * ((size_t)h.hs + (size_t)((a.K * h.csp + 4 * S + 3) & ~3) + 2 * kw) + sizeof(float) * 2 * NT * 16 + 1024;
     if (lds > 160 * 1024) return PBN_ERR_UNSUPPORTED;
-    auto kern = k_spconv_halo<T, NF, NT, RING>;
+    auto kern = k_spconv_halo<T, NW, NT, S, RING>;
     if (lds > 64 * 1024)
         PBN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(cdiv(a.n_out, TM), a.ntiles_total / NT), dim3(256), lds, stream, a, h);
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.n_out, TM), a.ntiles_total / NT), dim3(NW * 64), lds, stream, a, h);
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
 
-template <typename T, int NF>
-int launch_halo_nt(const ConvArgs& a, const HaloArgs& h, hipStream_t stream) {
-    static const int ring = getenv("PBN_HALO_RING") ? atoi(getenv("PBN_HALO_RING")) : 3;
+// cfg = 1000 * NW + 100 * S + 10 * RING + (NT code: channel tiles per workgroup, 0 = all when <= 8)
+template <typename T>
+int launch_halo_t(const ConvArgs& a, const HaloArgs& h, int nw, int s, int ring, hipStream_t stream) {
     const int ntt = a.ntiles_total;
-#define PBN_HALO_TRY(NTV)                                                                           \
-    if (ntt % NTV == 0)                                                                             \
-        return ring == 4 ? launch_halo_cfg<T, NF, NTV, 4>(a, h, stream) : launch_halo_cfg<T, NF, NTV, 3>(a, h, stream);
-    if (ntt <= 8) {
-        switch (ntt) {
-            case 8: PBN_HALO_TRY(8) break;
-            case 6: PBN_HALO_TRY(6) break;
-            case 4: PBN_HALO_TRY(4) break;
-            case 2: PBN_HALO_TRY(2) break;
-            default: break;
-        }
-    }
-    PBN_HALO_TRY(8)
-    PBN_HALO_TRY(6)
-    PBN_HALO_TRY(4)
-    PBN_HALO_TRY(2)
-#undef PBN_HALO_TRY
+    int nt = ntt <= 8 ? ntt : (ntt % 8 == 0 ? 8 : (ntt % 6 == 0 ? 6 : (ntt % 4 == 0 ? 4 : 2)));
+#define PBN_HALO_CASE(NWV, NTV, SV, RV) \
+    if (nw == NWV && nt == NTV && s == SV && ring == RV) return launch_halo_cfg<T, NWV, NTV, SV, RV>(a, h, stream);
+#define PBN_HALO_NT(NWV, SV, RV) PBN_HALO_CASE(NWV, 2, SV, RV) PBN_HALO_CASE(NWV, 4, SV, RV) PBN_HALO_CASE(NWV, 6, SV, RV) PBN_HALO_CASE(NWV, 8, SV, RV)
+    PBN_HALO_NT(4, 2, 2) PBN_HALO_NT(4, 3, 2) PBN_HALO_NT(4, 4, 2)
+    PBN_HALO_NT(8, 2, 2) PBN_HALO_NT(8, 3, 2) PBN_HALO_NT(8, 4, 2)
+    PBN_HALO_NT(4, 2, 3) PBN_HALO_NT(4, 3, 3) PBN_HALO_NT(4, 4, 3)
+    PBN_HALO_NT(8, 2, 3) PBN_HALO_NT(8, 3, 3) PBN_HALO_NT(8, 4, 3)
+#undef PBN_HALO_NT
+#undef PBN_HALO_CASE
     return PBN_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
 bool halo_supported(const ConvArgs& a, int tm) {
-    return tm == 128 && (a.vpo & 3) == 0 && a.K <= 128 && a.nbr != nullptr && a.row_perm == nullptr && (a.ntiles_total & 1) == 0;
+    return (tm == 128 || tm == 256) && (a.vpo & 3) == 0 && a.K <= 128 && a.nbr != nullptr && a.row_perm == nullptr &&
+           (a.ntiles_total & 1) == 0;
 }
 
+// cfg: 0 = automatic; else 100 * S + 10 * RING + CSP (units per iteration, ring slots, steps staged per pass)
 int launch_halo(const ConvArgs& a, int dtype, const int* cnt, const int* rows, const unsigned short* loc,
-                const unsigned short* fmask, int tm, int pitch, int hs, hipStream_t stream) {
+                const unsigned short* fmask, int tm, int pitch, int hs, int cfg, hipStream_t stream) {
     if (!halo_supported(a, tm)) return PBN_ERR_UNSUPPORTED;
     HaloArgs h;
     h.cnt = cnt; h.rows = rows; h.loc = loc; h.fmask = fmask; h.tm = tm; h.pitch = pitch;
     static const int hs_env = getenv("PBN_HALO_SLOTS") ? atoi(getenv("PBN_HALO_SLOTS")) : 0;
-    if (hs <= 0) hs = hs_env > 0 ? hs_env : (a.K > 27 ? 768 : 320);
+    static const int cfg_env = getenv("PBN_HALO_CFG") ? atoi(getenv("PBN_HALO_CFG")) : 0;
+    if (cfg <= 0) cfg = cfg_env;
+    const int nw = tm / 32;
+    if (hs <= 0) hs = hs_env > 0 ? hs_env : (a.K > 27 ? 3 * tm : (tm == 256 ? 480 : 352));
     h.hs = (hs + 15) & ~15;
     if (h.hs > HALO_MAX) h.hs = HALO_MAX;
+    const int spo = a.vpo >> 2;
+    int s = cfg > 0 ? cfg / 100 : 0, ring = cfg > 0 ? (cfg / 10) % 10 : 0, csp = cfg > 0 ? cfg % 10 : 0;
+    if (ring != 2 && ring != 3) ring = 2;
+    const int ntt = a.ntiles_total, nt = ntt <= 8 ? ntt : (ntt % 8 == 0 ? 8 : (ntt % 6 == 0 ? 6 : (ntt % 4 == 0 ? 4 : 2)));
+    const int KS = a.K | 1;
+    auto lds_of = [&](int sv, int cv) -> size_t {
+        return (size_t)ring * sv * nt * 1024 + (size_t)cv * (h.hs + 16) * 64 + 2 * (size_t)((tm * KS + 7) & ~7) +
+               4 * ((size_t)h.hs + (size_t)a.K * cv + 4 * sv + 2 * (a.K + 8)) + 8 * nt * 16 + 64 + 1024;
+    };
+    if (csp <= 0 || spo % csp) {
+        // as many steps per pass as fit (a divisor of the steps per offset, at most 4), 3 or 4 units per iteration
+        csp = 1;
+        for (int c = 4; c >= 1; --c)
+            if (spo % c == 0 && lds_of(c == 3 ? 3 : 4, c) <= (size_t)(tm == 256 ? 156 : 120) * 1024) { csp = c; break; }
+    }
+    if (s < 2 || s > 4) s = (csp == 3 || (csp == 1 && spo == 3)) ? 3 : 4;
+    h.csp = csp;
     switch (dtype) {
-        case PBN_F32: return launch_halo_nt<float, 2>(a, h, stream);
-        case PBN_BF16: return launch_halo_nt<__hip_bfloat16, 2>(a, h, stream);
-        case PBN_F16: return launch_halo_nt<__half, 2>(a, h, stream);
+        case PBN_F32: return launch_halo_t<float>(a, h, nw, s, ring, stream);
+        case PBN_BF16: return launch_halo_t<__hip_bfloat16>(a, h, nw, s, ring, stream);
+        case PBN_F16: return launch_halo_t<__half>(a, h, nw, s, ring, stream);
         default: return PBN_ERR_ARG;
     }
 }
 
 }  // namespace pbn
+
+#ifdef PBN_CONV_TIMING
+// debug build only: the stamps of the last k_spconv_halo launch -> host
+extern "C" int pbn_halo_timing_read(unsigned long long* host) {
+    PBN_HIP_CHECK(hipDeviceSynchronize());
+    PBN_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(pbn::g_halo_timing), sizeof(unsigned long long) * (pbn::HT_BLOCKS * 8 * pbn::HT_STAMPS + 8)));
+    return PBN_OK;
+}
+#endif
 
 using namespace pbn;
 
@@ -521,7 +628,7 @@ extern "C" int pbn_spconv_forward_halo(const void* in_feat, int ld_in, int n_in,
                                        const int32_t* n_out_dev, int n_out, const void* w_packed, int vecs_per_offset,
                                        int n_steps, int cout_padded, const float* scale, const float* shift,
                                        const void* residual, int ld_res, int relu, void* out_feat, int ld_out, int dtype,
-                                       const void* halo_table, const pbn_halo_layout* halo, int lds_slots,
+                                       const void* halo_table, const pbn_halo_layout* halo, int lds_slots, int cfg,
                                        pbn_stream_t stream) {
     if (n_out < 0 || n_in < 0 || n_offsets < 1 || vecs_per_offset < 4 || (vecs_per_offset & 3) || n_steps < 1 ||
         cout_padded < 16 || (cout_padded & 15) || !halo_table || !halo || !nbr)
@@ -547,5 +654,5 @@ extern "C" int pbn_spconv_forward_halo(const void* in_feat, int ld_in, int n_in,
     const char* A = (const char*)halo_table;
     return launch_halo(a, dtype, (const int*)(A + halo->cnt), (const int*)(A + halo->rows),
                        (const unsigned short*)(A + halo->loc), (const unsigned short*)(A + halo->fmask), halo->tile_rows,
-                       halo->pitch, lds_slots, (hipStream_t)stream);
+                       halo->pitch, lds_slots, cfg, (hipStream_t)stream);
 }

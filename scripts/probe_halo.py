@@ -14,6 +14,8 @@ torch.manual_seed(0)
 REP = 20
 STREAMS = int(os.environ.get("PBN_PROBE_STREAMS", "1"))
 SLOTS = [int(s) for s in os.environ.get("PBN_PROBE_SLOTS", "0").split(",")]
+TMS = [int(s) for s in os.environ.get("PBN_PROBE_TM", "128,256").split(",")]
+CFGS = [int(s) for s in os.environ.get("PBN_PROBE_CFG", "0").split(",")]
 DT = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[os.environ.get("PBN_PROBE_DTYPE", "bf16")]
 
 
@@ -56,20 +58,21 @@ tables = {}
 def run(level, cin, cout, k=3):
     n = pyr.n[level]
     nbr = pyr.kernel_map(1 << level, k)
-    if (level, k) not in tables:
+    for tm in TMS:
+        if (level, k, tm) in tables:
+            continue
         torch.cuda.synchronize()
-        HaloTable(nbr)
+        HaloTable(nbr, tile_rows=tm)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(5):
-            ht = HaloTable(nbr)
+            ht = HaloTable(nbr, tile_rows=tm)
         torch.cuda.synchronize()
         tb = (time.perf_counter() - t0) / 5 * 1e6
         cnt = ht.counts()
-        print("  tables L%d k=%d: %d rows, halo %.2fx, largest %d, build %.1f us (incl. allocation)" % (
-            level, k, n, cnt.sum().item() / n, cnt.max().item(), tb), flush=True)
-        tables[(level, k)] = ht
-    ht = tables[(level, k)]
+        print("  tables L%d k=%d tile %d: %d rows, halo %.2fx, largest %d, build %.1f us (incl. allocation)" % (
+            level, k, tm, n, cnt.sum().item() / n, cnt.max().item(), tb), flush=True)
+        tables[(level, k, tm)] = ht
     conv = ME.MinkowskiConvolution(cin, cout, kernel_size=k, dimension=3).to(dev)
     packed = conv._cache.get(conv.kernel, DT)
     e = 16 // torch.empty(0, dtype=DT).element_size()
@@ -78,14 +81,17 @@ def run(level, cin, cout, k=3):
     out2 = torch.empty_like(out)
     t_old = timed(lambda: spconv_forward(x, nbr, n, packed, out=out))
     line = "L%d rows=%6d %3d->%3d K=%3d: gather kernels %.1f us |" % (level, n, cin, cout, k ** 3, t_old)
-    for s in SLOTS:
-        try:
-            t_new = timed(lambda: spconv_forward_halo(x, ht, packed, out=out2, lds_slots=s))
-        except RuntimeError as ex:
-            line += " halo[%d] %s" % (s, ex)
-            continue
-        err = (out.float() - out2.float()).abs().max().item()
-        line += " halo[slots %d] %.1f us (x%.2f, diff %.2e)" % (s, t_new, t_old / t_new, err)
+    for tm in TMS:
+      ht = tables[(level, k, tm)]
+      for cfg in CFGS:
+        for s in SLOTS:
+            try:
+                t_new = timed(lambda: spconv_forward_halo(x, ht, packed, out=out2, lds_slots=s, cfg=cfg))
+            except RuntimeError as ex:
+                line += " [tile %d cfg %d slots %d] unsupported" % (tm, cfg, s)
+                continue
+            err = (out.float() - out2.float()).abs().max().item()
+            line += " [tile %d cfg %d slots %d] %.1f us (x%.2f, diff %.1e)" % (tm, cfg, s, t_new, t_old / t_new, err)
     print(line, flush=True)
 
 

@@ -32,27 +32,27 @@ def _maps(coords, k, order):
     return cm.kernel_map(1, k).contiguous(), np.arange(len(coords))
 
 
-@pytest.mark.parametrize("k", [3, 5])
+@pytest.mark.parametrize("k,tm", [(3, 128), (5, 128), (3, 256)])
 @pytest.mark.parametrize("order", ["sorted", "plain"])
-def test_halo_tables_match_numpy(k, order):
+def test_halo_tables_match_numpy(k, tm, order):
     coords = _coords(51)
     nbr, _ = _maps(coords, k, order)
     n, K = nbr.shape
-    ht = HaloTable(nbr)
+    ht = HaloTable(nbr, tile_rows=tm)
     L = ht.layout
-    assert L.tile_rows == 128 and L.n_offsets == K and L.tiles == (n + 127) // 128
+    assert L.tile_rows == tm and L.n_offsets == K and L.tiles == (n + tm - 1) // tm
     cnt = ht.counts().cpu().numpy()
     rows = ht.view("rows", torch.int32, L.tiles * L.pitch).cpu().numpy().reshape(L.tiles, L.pitch)
-    loc = ht.view("loc", torch.int16, L.tiles * 128 * K).cpu().numpy().view(np.uint16).reshape(L.tiles, 128, K)
+    loc = ht.view("loc", torch.int16, L.tiles * tm * K).cpu().numpy().view(np.uint16).reshape(L.tiles, tm, K)
     fm = ht.view("fmask", torch.int16, L.tiles * K).cpu().numpy().view(np.uint16).reshape(L.tiles, K)
     h = nbr.cpu().numpy()
     tot = 0
     for t in range(L.tiles):
-        blk = h[t * 128:(t + 1) * 128]
+        blk = h[t * tm:(t + 1) * tm]
         u = np.unique(blk[blk >= 0])
         assert cnt[t] == len(u), (t, cnt[t], len(u))
         assert np.array_equal(rows[t, :len(u)], u)
-        want = np.full((128, K), 0xffff, np.uint16)
+        want = np.full((tm, K), 0xffff, np.uint16)
         want[:len(blk)] = np.where(blk >= 0, np.searchsorted(u, np.maximum(blk, 0)), 0xffff).astype(np.uint16)
         assert np.array_equal(loc[t], want)
         wm = np.zeros(K, np.uint16)
@@ -60,7 +60,7 @@ def test_halo_tables_match_numpy(k, order):
             wm |= ((blk[f * 16:(f + 1) * 16] >= 0).any(0).astype(np.uint16) << f)
         assert np.array_equal(fm[t], wm)
         tot += len(u)
-    print("k=%d %s: %d rows, %d tiles, halo %.2fx, largest %d" % (k, order, n, L.tiles, tot / n, cnt.max()))
+    print("k=%d tile %d %s: %d rows, %d tiles, halo %.2fx, largest %d" % (k, tm, order, n, L.tiles, tot / n, cnt.max()))
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL), (torch.bfloat16, 6e-2), (torch.float16, 1e-2)])
@@ -90,15 +90,25 @@ def test_halo_convolution_matches_oracle(dtype, tol, cin, cout, k, order):
     resd[:, :cout] = res[perm].to(dtype).to(DEV)
     lim = tol if dtype == torch.float32 else tol * max(1.0, want.abs().max().item())
     want_p = want[perm]
-    full = HaloTable(nbr)
+    full, full256 = HaloTable(nbr), HaloTable(nbr, tile_rows=256)
     ref = spconv_forward(x, nbr, n, packed, scale=sc, shift=sh, residual=resd, relu=True)      # the round-1..3 kernels
+    spo = vpo // 4
+    cases = [("tile 128", full, 0, 0), ("tile 256", full256, 0, 0), ("48-slot buffer", full, 48, 0),
+             ("16-slot buffer, tile 256", full256, 16, 0), ("gather loop", HaloTable(nbr, max_rows=100), 0, 0)]
+    # explicit loop shapes: cfg = 100 * units per iteration + 10 * ring slots + steps staged per pass
+    for s_, r_, c_ in ((2, 2, 1), (3, 3, 1), (4, 2, 2), (3, 2, 3), (4, 3, 4), (2, 3, 2)):
+        if spo % c_ == 0:
+            cases.append(("cfg %d%d%d" % (s_, r_, c_), full if (s_ + r_) % 2 else full256, 0, 100 * s_ + 10 * r_ + c_))
     outs = []
-    for what, ht, slots in (("default", full, 0), ("48-slot buffer", full, 48), ("16-slot buffer", full, 16),
-                            ("gather loop", HaloTable(nbr, max_rows=100), 0)):
+    for what, ht, slots, cfg in cases:
         if what == "gather loop":
             assert int((ht.counts() < 0).sum().item()) > 0
-        o1 = spconv_forward_halo(x, ht, packed, scale=sc, shift=sh, residual=resd, relu=True, lds_slots=slots)
-        o2 = spconv_forward_halo(x, ht, packed, scale=sc, shift=sh, residual=resd, relu=True, lds_slots=slots)
+        try:
+            o1 = spconv_forward_halo(x, ht, packed, scale=sc, shift=sh, residual=resd, relu=True, lds_slots=slots, cfg=cfg)
+        except RuntimeError as ex:                 # a shape whose buffers exceed the LDS
+            assert "UNSUPPORTED" in str(ex) and cfg != 0, (what, ex)
+            continue
+        o2 = spconv_forward_halo(x, ht, packed, scale=sc, shift=sh, residual=resd, relu=True, lds_slots=slots, cfg=cfg)
         assert torch.equal(o1, o2), what + ": not deterministic"
         err = (o1[:, :cout].float().cpu() - want_p).abs().max().item()
         print("%d->%d k=%d %s %s [%s]: max |diff| %.3e (tol %.1e), vs the gather kernels %.3e" % (
@@ -133,7 +143,7 @@ def test_halo_capacity_and_device_count():
     out = torch.full((n, cout_p), 7.0, device=DEV)
     rc = N.lib().pbn_spconv_forward_halo(N.c_vp(x.data_ptr()), 32, n, N.c_vp(cap.data_ptr()), 27, N.c_vp(n_dev.data_ptr()), n,
                                          N.c_vp(w.data_ptr()), vpo, n_steps, cout_p, None, None, None, 0, 0,
-                                         N.c_vp(out.data_ptr()), cout_p, 0, N.c_vp(table.data_ptr()), ctypes.byref(lay), 0,
+                                         N.c_vp(out.data_ptr()), cout_p, 0, N.c_vp(table.data_ptr()), ctypes.byref(lay), 0, 0,
                                          N.current_stream())
     N.check(rc, "pbn_spconv_forward_halo")
     want = spconv_forward(x[:live].contiguous(), nb.contiguous(), live, packed)
