@@ -75,11 +75,33 @@ def build_model(device):
     return cfg, PBNet(cfg).to(device).eval()
 
 
-def build_scene(copies, dtype, device, workload="c2"):
+def pin_rank_to_cpus(local_rank, ranks_on_node):
+    """Before any GPU call: confine this rank (its 4 scene threads, the HIP runtime's helper threads) to its own contiguous
+    share of the host cores -- contiguous core ranges follow the NUMA nodes on the two-socket MI355X hosts, and 8 ranks x 4
+    threads must not migrate across sockets.  PBN_BENCH_PIN=0 switches it off; returns the core range or None."""
+    if os.environ.get("PBN_BENCH_PIN", "1") == "0" or ranks_on_node <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // ranks_on_node
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return [mine[0], mine[-1]]
+    except OSError:
+        return None
+
+
+def build_scene(copies, dtype, device, workload="c2", seed=None):
     from pbnet_amd import synth
-    # weak scaling: per-GPU work is fixed, so every rank holds its own copy of the SAME scene (other seeds of the
-    # generator give scenes of 148-161 k voxels, and the slowest rank would set the time of the whole job)
-    batch, teacher, info = synth.make_val_batch(copies=copies, **WORKLOADS[workload])
+    # one rank: the scene of BASELINE configs[1] (seed 2).  N ranks: rank r takes seed 10 + r (SURVEY.md C3 / C5: seeds 10-17) --
+    # distinct scenes of 148-161 k voxels, so the job's time is the slowest rank's (MAX over ranks) and per-rank rates are
+    # reported next to it
+    kw = dict(WORKLOADS[workload])
+    if seed is not None:
+        kw["seed"] = seed
+    batch, teacher, info = synth.make_val_batch(copies=copies, **kw)
     b = {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
     b["feat_voxel"] = b["feat_voxel"].to(dtype)
     # the teacher-forced head outputs stand in for slabs the path itself would hold in `dtype`: resident in that dtype
@@ -133,10 +155,72 @@ def timed_leg(model, b, t, inflight, device, steps, warmup=None, blocks=3):
     return steps / e, e / steps * 1e3, alone, r.result()
 
 
-def build_workload(rank, copies, dtype, device, workload="c2"):
+def build_workload(rank, copies, dtype, device, workload="c2", world=1):
     cfg, model = build_model(device)
-    b, t, info, raw = build_scene(copies, dtype, device, workload)
+    b, t, info, raw = build_scene(copies, dtype, device, workload, seed=(10 + rank) if world > 1 else None)
     return cfg, model, b, t, info, raw
+
+
+def planned_leg(model, b, t, dtype, inflight, device, steps, graph):
+    """The sync-free forward (pbnet_amd/planned.py: every data-dependent size stays on the device) on `inflight` streams, eager
+    launch sequence or HIP-graph replay: scenes/s, and one scene alone in ms.  The difference to the headline (the eager
+    forward with its three read-backs) is what the host costs."""
+    from pbnet_amd import planned
+    args = (b["feat_voxel"].to(dtype), b["xyz_voxel"], b["xyz_original"], b["v2p_index"])
+    cap = planned.measure_capacities(model, *args, teacher=t).padded(1.25)
+    streams = [torch.cuda.Stream(device) for _ in range(inflight)]
+    pfs = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            pf = planned.PlannedForward(model, cap, dtype=dtype)
+            pf(*args, teacher=t)
+            if graph:
+                pf.capture(*args, teacher=t)
+            pfs.append(pf)
+        torch.cuda.synchronize()
+    errors = []
+
+    def step(i):
+        return pfs[i].finish(pfs[i].replay()) if graph else pfs[i](*args, teacher=t)
+
+    def run(n, m):
+        def worker(i):
+            try:
+                torch.cuda.set_device(device)
+                with torch.cuda.stream(streams[i]):
+                    for _ in range(i, n, m):
+                        step(i)
+                    streams[i].synchronize()
+            except BaseException as e:
+                errors.append(e)
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(m)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if errors:
+            raise errors[0]
+    run(2 * inflight, inflight)
+    bl = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps, inflight)
+        torch.cuda.synchronize()
+        bl.append(time.perf_counter() - t0)
+    e = float(np.median(bl))
+    run(3, 1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run(8, 1)
+    torch.cuda.synchronize()
+    alone = (time.perf_counter() - t1) / 8 * 1e3
+    out = step(0)
+    torch.cuda.synchronize()
+    finite = bool(torch.isfinite(out["clt_scores"].float()).all()) if out["clt_scores"].numel() else True
+    return {"value": round(steps / e, 3), "unit": "scenes/s", "ms_per_step": round(e / steps * 1e3, 3),
+            "scenes_in_flight": inflight, "one_scene_in_flight_ms_per_scene": round(alone, 3),
+            "proposals_per_step": int(out["proposals"][1].shape[0] - 1), "finite": finite}
 
 
 def one_step(model, b, t):
@@ -436,6 +520,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    pinned = pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))   # before anything touches the GPU
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -446,7 +531,7 @@ def main():
     phase("rccl_init")
 
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
-    cfg, model, b, t, info, raw = build_workload(rank, args.copies, dtype, device, args.workload)
+    cfg, model, b, t, info, raw = build_workload(rank, args.copies, dtype, device, args.workload, world)
     phase("build_workload")
 
     def barrier():
@@ -461,11 +546,13 @@ def main():
     runner.run(args.inflight)               # every stream allocates its scratch and allocator pools once
     phase("first_steps")
     runner.run(args.warmup)
-    blocks = []
+    blocks, own_blocks = [], []
     for _ in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
         runner.run(args.steps)              # EXACTLY K steps
+        torch.cuda.synchronize()
+        own_blocks.append(time.perf_counter() - t0)      # this rank's own steps, before it waits for the others
         barrier()
         el = time.perf_counter() - t0
         if dist is not None:
@@ -473,6 +560,13 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         blocks.append(el)
+    per_rank = None
+    if dist is not None and world > 1:
+        mine = torch.tensor([args.steps / float(np.median(own_blocks)), float(info["n_voxels"])], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"scenes_per_s": [round(float(x[0]), 2) for x in allr], "voxels": [int(x[1]) for x in allr]}
+        per_rank["min"], per_rank["max"] = min(per_rank["scenes_per_s"]), max(per_rank["scenes_per_s"])
     phase("warmup_and_timed_blocks")
     elapsed = float(np.median(blocks))
     rate = lambda e: world * args.steps / e
@@ -588,12 +682,24 @@ def main():
                 # fp32 = the parity configuration (1e-4 against the oracle is asserted in fp32: tests/test_bench_workload_gpu.py)
                 k = max(args.inflight, args.steps // 3)
                 b32 = dict(b, feat_voxel=b["feat_voxel"].float())
-                v, ms, alone, _ = timed_leg(model, b32, t, args.inflight, device, k)
+                t32 = {k_: torch.from_numpy(v_).to(device) for k_, v_ in raw[1].items()}     # the teacher in fp32 too (not the 16-bit copy)
+                v, ms, alone, _ = timed_leg(model, b32, t32, args.inflight, device, k)
                 legs["fp32"] = {"value": round(v, 3), "unit": "scenes/s", "ms_per_step": round(ms, 3),
                                 "one_scene_in_flight_ms_per_scene": round(alone, 3), "dtype": "f32",
                                 "note": "configs[1] with fp32 feature slabs (v_mfma_f32_16x16x4_f32): the configuration the "
                                         "1e-4 parity tests run in"}
-                del b32
+                del b32, t32
+                # configs[4]: fp16 feature slabs, int32 coordinates, the WHOLE forward replayed from a HIP graph (planned.py), one
+                # graph per stream; and the same sync-free forward in the headline's dtype, eager and from graphs: the distance
+                # to the headline is the host's share (three read-backs + the Python of the eager forward)
+                legs["graph_f16"] = planned_leg(model, b, t, torch.float16, args.inflight, device, k, graph=True)
+                legs["graph_f16"]["note"] = ("configs[4]: fp16 slabs + int32 coordinates, MinkUNet34C, whole PBNet.forward from a HIP "
+                                             "graph per stream (capacity-planned forward, no host read-back inside)")
+                legs["planned"] = {"eager": planned_leg(model, b, t, dtype, args.inflight, device, k, graph=False),
+                                   "graph": planned_leg(model, b, t, dtype, args.inflight, device, k, graph=True),
+                                   "note": "the sync-free forward in the headline's dtype; headline = eager PBNet.forward with its "
+                                           "read-backs"}
+                phase("planned_legs")
                 # three DISTINCT scenes per forward through the batch index: every launch of the coarse levels gets 3x the rows
                 bb, tb, ib = build_batched((2, 4, 5), dtype, device)
                 v, ms, alone, rb = timed_leg(model, bb, tb, args.inflight, device, max(args.inflight, k // 2))
@@ -660,9 +766,13 @@ def main():
                        "one_scene_in_flight_ms_per_scene": None if single_ms is None else round(single_ms, 3),
                        "parallelism": "scenes sharded over GPUs, %d in flight per GPU (host thread + HIP stream each), "
                                       "no data-path collective" % args.inflight,
+                       "scene_seeds": "2 (configs[1])" if world == 1 else "10 + rank (SURVEY C3/C5)",
+                       "cpu_pinning": pinned,
                        "rccl": rccl_status},
             "roofline": roof,
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
         if stages is not None:
             line["stages_ms"] = stages
             line["grouping"] = grouping

@@ -202,10 +202,13 @@ typedef struct {
 size_t pbn_halo_bytes(int n_out, int n_offsets, int tile_rows, pbn_halo_layout* layout);
 /* the tables of up to 16 maps in ONE launch */
 int pbn_halo_build(const pbn_halo_job* jobs, int n_jobs, pbn_stream_t stream);
-/* pbn_spconv_forward over a map with halo tables (tile_rows 128 or 256; vecs_per_offset a multiple of 4; no row_perm).
+/* pbn_spconv_forward over a map with halo tables (tile_rows 32 / 64: K split over the waves of a workgroup, 128 / 256: a
+ * wave per 32 / 64 rows; vecs_per_offset a multiple of 4; no row_perm).
  * lds_slots: rows of the LDS buffer (0 = default); a tile with more distinct rows runs once per segment of its list.
- * cfg: 0 = automatic, else 100 * S + 10 * RING + CSP (reduction units per loop iteration 2..4, weight ring slots 2..3,
- * 64-byte pieces of a row staged per pass: a divisor of vecs_per_offset / 4) -- explicit values for tests and tuning.
+ * cfg: 0 = automatic; > 0: 10000 * depth + (1000 * ksplit + 100 * NF + NT), the configuration code of the wave-autonomous
+ * family (pbn_spconv_forward, rows_per_wave >= 100) whose tile must match tile_rows, depth = weight stages in flight (0, 2,
+ * 3); < 0: the barrier-synchronised experiment of csrc/spconv_halo.hip, -(100 * S + 10 * RING + CSP) -- explicit values
+ * for tests and tuning.
  * PBN_ERR_UNSUPPORTED for shapes this family does not build (the caller falls back to pbn_spconv_forward). */
 int pbn_spconv_forward_halo(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
                             const int32_t* n_out_dev, int n_out, const void* w_packed, int vecs_per_offset, int n_steps,

@@ -167,6 +167,7 @@ class CoordinateManager(object):
                                         N.current_stream())
             N.check(rc, "pbn_coords_prepare")
             self._native = (arena, P)
+            self._prepare_input = coords            # kept until the counts are read: a key-bits failure retries through the hash pipeline
             sv = SortedView()
             sv.pyramid = _Pyramid(None, None, n, _prepared=(arena, P.pyramid))
             sv.perm = sv.inv_perm = None
@@ -218,6 +219,15 @@ class CoordinateManager(object):
             arena, P = self._native
             pyr = self._sorted.pyramid
             counts = pyr.counts_dev.tolist()                                           # the one host read
+            if min(counts) < 0 and self.__dict__.get("_prepare_input") is not None:
+                # the sorted pipeline refuses boxes whose Z-order key needs more than 44 bits (very wide scenes, large batch
+                # ranges); the hash-table pipeline takes any in-range 16-bit coordinates and fills the same arena and layout
+                coords = self._prepare_input
+                rc = N.lib().pbn_coords_prepare_hash(N.ptr(coords), None, self.n_input, 1, int(CV.X_FASTEST), N.ptr(arena),
+                                                     arena.numel(), ctypes.byref(P), N.current_stream())
+                N.check(rc, "pbn_coords_prepare_hash")
+                counts = pyr.counts_dev.tolist()
+            self._prepare_input = None
             pyr.set_counts(counts)
             n1 = self._n1 = int(counts[0])
             n = self.n_input

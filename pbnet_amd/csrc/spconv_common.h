@@ -118,4 +118,9 @@ bool halo_supported(const ConvArgs& a, int tile_rows);
 int launch_halo(const ConvArgs& a, int dtype, const int* cnt, const int* rows, const unsigned short* loc,
                 const unsigned short* fmask, int tile_rows, int pitch, int lds_slots, int cfg, hipStream_t stream);
 
+// spconv_wave_halo.hip: the wave-autonomous family with LDS-staged rows; cfg = 1000 * ksplit + 100 * NF + NT as spconv_wave.hip
+int wh_tile_rows(int cfg);
+int launch_wave_halo(const ConvArgs& a, int dtype, const int* cnt, const int* rows, const unsigned short* loc,
+                     const unsigned short* fmask, int tile_rows, int pitch, int lds_slots, int cfg, int depth, hipStream_t stream);
+
 }  // namespace pbn

@@ -652,6 +652,28 @@ extern "C" int pbn_spconv_forward_halo(const void* in_feat, int ld_in, int n_in,
     static const int dbg_env = getenv("PBN_HALO_DBG") ? atoi(getenv("PBN_HALO_DBG")) : 0;   // ablations (results are garbage): 1 no weight DMA, 2 no MFMA, 4 no barriers, 8 no row staging
     a.dbg = dbg_env;
     const char* A = (const char*)halo_table;
+    if (cfg >= 0) {
+        // the wave-autonomous family with staged rows (spconv_wave_halo.hip); 0 = by tile height and channel tiles
+        int depth = cfg / 10000, wcfg = cfg % 10000;
+        if (wcfg == 0) {
+            const int ntt = a.ntiles_total, tr = halo->tile_rows;
+            const int nt = ntt % 8 == 0 ? 8 : (ntt % 6 == 0 ? 6 : (ntt % 4 == 0 ? 4 : (ntt % 2 == 0 ? 2 : 1)));
+            if (tr == 32 || tr == 64) {
+                // K-split: the narrowest channel tile that still gives ~a workgroup per CU keeps the weight stream per workgroup short
+                const long long tiles = (n_out + tr - 1) / tr;
+                int pick = nt;
+                for (int c : {8, 4, 2, 1})
+                    if (ntt % c == 0 && c <= nt) { pick = c; if (tiles * (ntt / c) >= 180) break; }
+                wcfg = 1000 + (tr / 16) * 100 + pick;
+            } else if (tr == 128 || tr == 256) {
+                wcfg = (tr / 64) * 100 + (nt == 1 ? 2 : nt);
+            } else return PBN_ERR_UNSUPPORTED;
+        }
+        return launch_wave_halo(a, dtype, (const int*)(A + halo->cnt), (const int*)(A + halo->rows),
+                                (const unsigned short*)(A + halo->loc), (const unsigned short*)(A + halo->fmask), halo->tile_rows,
+                                halo->pitch, lds_slots, wcfg, depth, (hipStream_t)stream);
+    }
+    cfg = -cfg;
     return launch_halo(a, dtype, (const int*)(A + halo->cnt), (const int*)(A + halo->rows),
                        (const unsigned short*)(A + halo->loc), (const unsigned short*)(A + halo->fmask), halo->tile_rows,
                        halo->pitch, lds_slots, cfg, (hipStream_t)stream);

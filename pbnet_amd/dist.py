@@ -95,18 +95,33 @@ class GradientReducer(object):
         # rank constructs its reducer at the same point (as it must for the buckets to match).
         self._host_group = None
         if self.world > 1 and dist.get_backend() != "gloo" and os.environ.get("PBN_REDUCER_HOST_GROUP", "1") != "0":
-            try:
-                self._host_group = dist.new_group(backend="gloo")
-            except Exception:                   # no gloo in this build: the device path below
-                self._host_group = None
+            self._host_group = _shared_host_group()
         if overlap and self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def wire_stats(self):
+        """(buckets, bytes each rank puts on the wire per step, parameters): what a step's all-reduces move."""
+        esz = torch.empty(0, dtype=self.comm_dtype).element_size()
+        return {"buckets": len(self.buckets), "bytes_per_step": int(sum(b["numel"] for b in self.buckets) * esz),
+                "parameters": len(self.params), "largest_bucket_bytes": int(max([b["numel"] for b in self.buckets] + [0]) * esz),
+                "host_group_for_used_flags": self._host_group is not None}
 
     def remove_hooks(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+    def reset(self):
+        """Forget the gradients of a backward whose step is being SKIPPED (a non-finite loss followed by `continue`): without
+        it the next backward would find its buckets filled and raise.  Every rank must skip the same steps -- the collectives
+        of a step are issued in finish() (and from the hooks) on all ranks or on none: buckets that already went on the wire are
+        waited for here so that the next step starts with a clean queue."""
+        for b in self.buckets:
+            if b["work"] is not None:
+                b["work"].wait()
+            b["work"], b["pending"], b["filled"] = None, len(b["params"]), [False] * len(b["params"])
+        self._next = 0
 
     # ---- per-gradient path (called by autograd during backward) ----------------------------------------------------
     def _flat(self, b, like):
@@ -171,6 +186,39 @@ class GradientReducer(object):
                     p.grad.copy_(g / self.world)
             b["work"], b["pending"], b["filled"] = None, len(b["params"]), [False] * len(b["params"])
         return len(self.buckets)
+
+
+_HOST_GROUP = {"made": False, "group": None}
+
+
+def _shared_host_group():
+    """ONE host-side (gloo) group per process, created at the first reducer and kept (round 3 made one per reducer and never
+    destroyed it).  Whether it exists is agreed COLLECTIVELY: a rank whose gloo group failed must not take the device path
+    while the others use the host group -- the all-reduces would mismatch and hang."""
+    if _HOST_GROUP["made"]:
+        return _HOST_GROUP["group"]
+    grp, ok = None, 1
+    try:
+        grp = dist.new_group(backend="gloo")
+    except Exception:                           # no gloo in this build
+        grp, ok = None, 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device())
+                        if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)             # default group: every rank takes part whatever happened above
+    if int(flag.item()) == 0:
+        grp = None
+    _HOST_GROUP["made"], _HOST_GROUP["group"] = True, grp
+    return grp
+
+
+def close_host_group():
+    """Destroy the shared host group (call before dist.destroy_process_group())."""
+    if _HOST_GROUP["group"] is not None:
+        try:
+            dist.destroy_process_group(_HOST_GROUP["group"])
+        except Exception:
+            pass
+    _HOST_GROUP["made"], _HOST_GROUP["group"] = False, None
 
 
 def allreduce_gradients(params, bucket_bytes=64 << 20, comm_dtype=torch.float32):

@@ -5,6 +5,10 @@
 //   mode 2: quad-coalesced      -- lane (r = l / 4, c = l % 4)  reads 16 B at row[r] + 16 c      (16 lines / instruction)
 //   mode 3: as mode 1, every lane out of range (returns zeros)
 //   mode 4: as mode 2 through the LDS-DMA path (buffer_load_dwordx4 ... lds), no VGPR destination
+//   mode 5: MFMA operand layout over a FRAGMENT-BLOCKED slab -- 16 consecutive rows interleaved per 16-byte chunk: chunk c of row
+//           r lives at (r / 16) * 16 * row_bytes + c * 256 + (r % 16) * 16 -- with the 16 rows of a fragment in RUNS of `runlen`
+//           consecutive rows from random starts (round 4: would consecutive neighbour rows coalesce again?)
+//   mode 6: as mode 1 (row-major slab) with the same runs (control: runs alone buy nothing in a row-major slab)
 // build: hipcc --offload-arch=gfx950 -O3 gather_layout.hip -o gather_layout ; run: ./gather_layout [row_bytes]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,7 +19,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
 __global__ __launch_bounds__(512) void k(const unsigned char* slab, unsigned slab_bytes, int n_rows, int row_bytes,
-                                         const int* rows, int iters, unsigned* sink, unsigned long long* cyc) {
+                                         const int* rows, int iters, unsigned* sink, unsigned long long* cyc, int runlen) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[8 * 4096];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long addr = (unsigned long long)slab;
@@ -38,6 +42,12 @@ __global__ __launch_bounds__(512) void k(const unsigned char* slab, unsigned sla
             unsigned voff;
             if (MODE == 0) voff = (row_of(i + j, 0) * (unsigned)row_bytes) / 1024u * 1024u + lane * 16;
             else if (MODE == 1 || MODE == 3) voff = row_of(i + j, lane & 15) * (unsigned)row_bytes + (lane >> 4) * 16;
+            else if (MODE == 5 || MODE == 6) {
+                const int r = lane & 15;
+                const unsigned row = row_of(i + j, r / runlen) + (unsigned)(r % runlen);     // runs of runlen consecutive rows
+                if (MODE == 5) voff = (row >> 4) * 16u * (unsigned)row_bytes + (unsigned)(lane >> 4) * 256u + (row & 15u) * 16u;
+                else voff = row * (unsigned)row_bytes + (lane >> 4) * 16;
+            }
             else voff = row_of(i + j, lane >> 2) * (unsigned)row_bytes + (lane & 3) * 16;
             if (MODE == 3) voff = 0x80000000u;
             if (MODE == 4) {
@@ -73,8 +83,8 @@ int main(int argc, char** argv) {
     hipMalloc(&rows, h.size() * 4); hipMemcpy(rows, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMalloc(&sink, 16); hipMalloc(&cyc, wgs * 8 * 8);
     std::vector<unsigned long long> hc(wgs * 8);
-    auto run = [&](auto kern, const char* name) {
-        for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), 0, 0, slab, slab_bytes, n_rows, row_bytes, rows, iters, sink, cyc);
+    auto run = [&](auto kern, const char* name, int runlen = 1) {
+        for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), 0, 0, slab, slab_bytes, n_rows, row_bytes, rows, iters, sink, cyc, runlen);
         hipDeviceSynchronize();
         hipMemcpy(hc.data(), cyc, hc.size() * 8, hipMemcpyDeviceToHost);
         double s = 0; for (auto c : hc) s += (double)c;
@@ -88,5 +98,15 @@ int main(int argc, char** argv) {
     run(k<2>, "2 quad-coalesced (16 rows x 64 B)");
     run(k<3>, "3 MFMA layout, all lanes out of range");
     run(k<4>, "4 quad-coalesced through LDS-DMA");
+    for (int rl : {1, 2, 4, 8, 16}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "5 MFMA layout, blocked slab, runs of %d", rl);
+        run(k<5>, nm, rl);
+    }
+    for (int rl : {4, 16}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "6 MFMA layout, row-major slab, runs of %d", rl);
+        run(k<6>, nm, rl);
+    }
     return 0;
 }

@@ -14,7 +14,7 @@ torch.manual_seed(0)
 REP = 20
 STREAMS = int(os.environ.get("PBN_PROBE_STREAMS", "1"))
 SLOTS = [int(s) for s in os.environ.get("PBN_PROBE_SLOTS", "0").split(",")]
-TMS = [int(s) for s in os.environ.get("PBN_PROBE_TM", "128,256").split(",")]
+TMS = [int(s) for s in os.environ.get("PBN_PROBE_TM", "32,64,128,256").split(",")]
 CFGS = [int(s) for s in os.environ.get("PBN_PROBE_CFG", "0").split(",")]
 DT = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[os.environ.get("PBN_PROBE_DTYPE", "bf16")]
 
@@ -56,8 +56,18 @@ tables = {}
 
 
 def run(level, cin, cout, k=3):
-    n = pyr.n[level]
-    nbr = pyr.kernel_map(1 << level, k)
+    # k = 3 / 5: cube maps at `level`; k = 2: the k2s2 down convolution from `level` to level + 1; k = -2: the transposed one
+    # from level + 1 up to `level`
+    if k == 2:
+        nbr, n = pyr.down_map(1 << level), pyr.n[level + 1]
+        n_in = pyr.n[level]
+    elif k == -2:
+        nbr, n = pyr.up_map(2 << level), pyr.n[level]
+        n_in = pyr.n[level + 1]
+    else:
+        n = n_in = pyr.n[level]
+        nbr = pyr.kernel_map(1 << level, k)
+    nbr = nbr.contiguous()
     for tm in TMS:
         if (level, k, tm) in tables:
             continue
@@ -71,16 +81,22 @@ def run(level, cin, cout, k=3):
         tb = (time.perf_counter() - t0) / 5 * 1e6
         cnt = ht.counts()
         print("  tables L%d k=%d tile %d: %d rows, halo %.2fx, largest %d, build %.1f us (incl. allocation)" % (
-            level, k, tm, n, cnt.sum().item() / n, cnt.max().item(), tb), flush=True)
+            level, k, tm, n, cnt.sum().item() / n, cnt.max().item(), tb), flush=True) if os.environ.get('PBN_PROBE_VERBOSE') else None
         tables[(level, k, tm)] = ht
-    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=k, dimension=3).to(dev)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=abs(k), dimension=3).to(dev)
     packed = conv._cache.get(conv.kernel, DT)
     e = 16 // torch.empty(0, dtype=DT).element_size()
-    x = torch.randn(n, packed[1] * e, device=dev).to(DT)
+    x = torch.randn(n_in, packed[1] * e, device=dev).to(DT)
     out = torch.empty(n, packed[3], dtype=DT, device=dev)
     out2 = torch.empty_like(out)
     t_old = timed(lambda: spconv_forward(x, nbr, n, packed, out=out))
-    line = "L%d rows=%6d %3d->%3d K=%3d: gather kernels %.1f us |" % (level, n, cin, cout, k ** 3, t_old)
+    line = "L%d rows=%6d %3d->%3d K=%3d: gather kernels %.1f us |" % (level, n, cin, cout, abs(k) ** 3, t_old)
+    for rpw in [int(v) for v in os.environ.get("PBN_PROBE_OLD_CFG", "").split(",") if v]:
+        try:
+            line += " old[%d] %.1f" % (rpw, timed(lambda: spconv_forward(x, nbr, n, packed, out=out, rows_per_wave=rpw)))
+        except RuntimeError:
+            line += " old[%d] n/a" % rpw
+    best = None
     for tm in TMS:
       ht = tables[(level, k, tm)]
       for cfg in CFGS:
@@ -91,7 +107,11 @@ def run(level, cin, cout, k=3):
                 line += " [tile %d cfg %d slots %d] unsupported" % (tm, cfg, s)
                 continue
             err = (out.float() - out2.float()).abs().max().item()
-            line += " [tile %d cfg %d slots %d] %.1f us (x%.2f, diff %.1e)" % (tm, cfg, s, t_new, t_old / t_new, err)
+            line += " [%d/%d/%d] %.1f (%.0e)" % (tm, cfg, s, t_new, err)
+            if best is None or t_new < best[0]:
+                best = (t_new, tm, cfg)
+    if best:
+        line += "  BEST tile %d cfg %d: %.1f us = x%.2f" % (best[1], best[2], best[0], t_old / best[0])
     print(line, flush=True)
 
 

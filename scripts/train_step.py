@@ -103,7 +103,8 @@ def run_training(world, rank, dev, dist, steps=5, warmup=2, dtype=None, comm_dty
         phases_out.update({k: v / 5 * 1e3 for k, v in phases.items()})
     if dist is not None and dist.is_initialized():
         pd.sync_buffers(model)                                      # what precedes validation / checkpoint_save
-    return elapsed, t_comm[0] / max(steps, 1), float(loss), info
+    info = dict(info, reducer=reducer.wire_stats())
+    return elapsed, t_comm[0] / max(steps, 1), float(loss.detach()), info
 
 
 def dry_run(args):
@@ -201,7 +202,10 @@ def main():
                           "ms_per_step": round(e / args.steps * 1e3, 2), "dtype": args.dtype, "comm_dtype": args.comm_dtype,
                           "allreduce_tail_ms_per_step": round(comm * 1e3, 2), "overlap": not args.no_overlap,
                           "mean_loss_last_step": round(float(lossv) / world, 5),
-                          "points_per_scene": info["n_points"], "voxels_per_scene": info["n_voxels"]}), flush=True)
+                          "points_per_scene": info["n_points"], "voxels_per_scene": info["n_voxels"],
+                          "gradient_buckets": info["reducer"]["buckets"], "bytes_on_the_wire_per_rank_per_step": info["reducer"]["bytes_per_step"],
+                          "largest_bucket_bytes": info["reducer"]["largest_bucket_bytes"],
+                          "used_flags_over_host_group": info["reducer"]["host_group_for_used_flags"]}), flush=True)
 
 
 if __name__ == "__main__":

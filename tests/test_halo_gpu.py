@@ -32,7 +32,7 @@ def _maps(coords, k, order):
     return cm.kernel_map(1, k).contiguous(), np.arange(len(coords))
 
 
-@pytest.mark.parametrize("k,tm", [(3, 128), (5, 128), (3, 256)])
+@pytest.mark.parametrize("k,tm", [(3, 128), (5, 128), (3, 256), (3, 32), (3, 64)])
 @pytest.mark.parametrize("order", ["sorted", "plain"])
 def test_halo_tables_match_numpy(k, tm, order):
     coords = _coords(51)
@@ -57,7 +57,7 @@ def test_halo_tables_match_numpy(k, tm, order):
         assert np.array_equal(loc[t], want)
         wm = np.zeros(K, np.uint16)
         for f in range((len(blk) + 15) // 16):
-            wm |= ((blk[f * 16:(f + 1) * 16] >= 0).any(0).astype(np.uint16) << f)
+            wm |= ((blk[f * 16:(f + 1) * 16] >= 0).any(0).astype(np.uint16) << np.uint16(f))
         assert np.array_equal(fm[t], wm)
         tot += len(u)
     print("k=%d tile %d %s: %d rows, %d tiles, halo %.2fx, largest %d" % (k, tm, order, n, L.tiles, tot / n, cnt.max()))
@@ -90,23 +90,35 @@ def test_halo_convolution_matches_oracle(dtype, tol, cin, cout, k, order):
     resd[:, :cout] = res[perm].to(dtype).to(DEV)
     lim = tol if dtype == torch.float32 else tol * max(1.0, want.abs().max().item())
     want_p = want[perm]
-    full, full256 = HaloTable(nbr), HaloTable(nbr, tile_rows=256)
+    tabs = {tm: HaloTable(nbr, tile_rows=tm) for tm in (32, 64, 128, 256)}
+    full, full256 = tabs[128], tabs[256]
     ref = spconv_forward(x, nbr, n, packed, scale=sc, shift=sh, residual=resd, relu=True)      # the round-1..3 kernels
     spo = vpo // 4
-    cases = [("tile 128", full, 0, 0), ("tile 256", full256, 0, 0), ("48-slot buffer", full, 48, 0),
-             ("16-slot buffer, tile 256", full256, 16, 0), ("gather loop", HaloTable(nbr, max_rows=100), 0, 0)]
-    # explicit loop shapes: cfg = 100 * units per iteration + 10 * ring slots + steps staged per pass
+    # the wave-autonomous family with staged rows (csrc/spconv_wave_halo.hip): automatic configuration per tile height, small
+    # LDS buffers (several segments per tile), marked tiles (plain gather loop), every built configuration
+    cases = [("tile %d" % tm, tabs[tm], 0, 0) for tm in (32, 64, 128, 256)]
+    cases += [("48-slot buffer", full, 48, 0), ("16-slot buffer, tile 256", full256, 16, 0), ("32-slot buffer, tile 32", tabs[32], 32, 0),
+              ("gather loop", HaloTable(nbr, max_rows=100), 0, 0), ("gather loop, tile 64", HaloTable(nbr, tile_rows=64, max_rows=60), 0, 0)]
+    ntt = cout_p // 16
+    for code in (402, 404, 406, 408, 202, 204, 206, 208, 1401, 1402, 1404, 1408, 1201, 1202, 1204, 1208):
+        nf, nt = (code // 100) % 10, code % 100
+        if ntt % nt:
+            continue
+        tm = nf * 16 if code >= 1000 else nf * 64
+        for depth in (2, 3):
+            cases.append(("cfg %d depth %d" % (code, depth), tabs[tm], 0, 10000 * depth + code))
+    # the barrier-synchronised experiment (csrc/spconv_halo.hip): -(100 * units per iteration + 10 * ring slots + steps per pass)
     for s_, r_, c_ in ((2, 2, 1), (3, 3, 1), (4, 2, 2), (3, 2, 3), (4, 3, 4), (2, 3, 2)):
         if spo % c_ == 0:
-            cases.append(("cfg %d%d%d" % (s_, r_, c_), full if (s_ + r_) % 2 else full256, 0, 100 * s_ + 10 * r_ + c_))
+            cases.append(("barrier cfg %d%d%d" % (s_, r_, c_), full if (s_ + r_) % 2 else full256, 0, -(100 * s_ + 10 * r_ + c_)))
     outs = []
     for what, ht, slots, cfg in cases:
-        if what == "gather loop":
+        if what.startswith("gather loop"):
             assert int((ht.counts() < 0).sum().item()) > 0
         try:
             o1 = spconv_forward_halo(x, ht, packed, scale=sc, shift=sh, residual=resd, relu=True, lds_slots=slots, cfg=cfg)
-        except RuntimeError as ex:                 # a shape whose buffers exceed the LDS
-            assert "UNSUPPORTED" in str(ex) and cfg != 0, (what, ex)
+        except RuntimeError as ex:                 # a shape whose buffers exceed the LDS (or a configuration that is not built)
+            assert "UNSUPPORTED" in str(ex) and (cfg != 0 or k == 5), (what, ex)
             continue
         o2 = spconv_forward_halo(x, ht, packed, scale=sc, shift=sh, residual=resd, relu=True, lds_slots=slots, cfg=cfg)
         assert torch.equal(o1, o2), what + ": not deterministic"

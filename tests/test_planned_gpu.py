@@ -192,3 +192,59 @@ def test_bench_scene_planned_bf16():
         elif it == 2:
             _ = torch.ones(1 << 20, device=DEV).sum().item()
     # timings of the three forms live in scripts/debug_planned.py / scripts/debug_inflight_graph.py
+
+
+def test_bench_scene_whole_forward_fp16_graph_configs4():
+    """BASELINE configs[4] AT ITS SIZE: fp16 feature slabs + int32 coordinates, MinkUNet34C, the whole PBNet.forward of the bench
+    scene (seed 2: 161 517 points / 146 038 voxels) captured in a HIP graph (reference shape: eval_map.py:48-50, one scene per
+    forward).  Contract, stated here and asserted below:
+      * graph replay == the eager planned launch sequence, bit for bit (integer outputs and fp16 scores), over several replays;
+      * no inf / NaN anywhere in the outputs (fp16 has 5 exponent bits: an overflow of a 150 k-voxel activation with random-init
+        weights would show up here);
+      * eager fp16 against the fp32 forward of the same model, which tests/test_bench_workload_gpu.py pins to the oracle
+        (oracle/pbnet_ref.py) at 1e-4: the same local scenes survive, the same number of proposals, proposal membership differs
+        on at most FP16_MEMBERSHIP_BOUND of the fp32 rows, clt_scores within FP16_SCORE_TOL."""
+    FP16_MEMBERSHIP_BOUND = 1e-3
+    FP16_SCORE_TOL = 3e-3
+    cfg = get_config(test=True)
+    torch.manual_seed(22)
+    model = PBNet(cfg).to(DEV).eval()
+    batch, teacher, info = synth.make_val_batch(seed=2, copies=1)
+    assert info["n_points"] == 161517 and info["n_voxels"] == 146038
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in batch.items()}
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in teacher.items()}
+    r32 = _eager(model, b, t)
+    b["feat_voxel"] = b["feat_voxel"].to(torch.float16)
+    r16 = _eager(model, b, t)
+    for k, v in r16.items():
+        if torch.is_tensor(v) and v.is_floating_point():
+            assert bool(torch.isfinite(v.float()).all()), "non-finite values in " + k
+    i32, o32, v32, _ = r32["proposals"]
+    i16, o16, v16, m16 = r16["proposals"]
+    assert bool(torch.isfinite(m16.float()).all())
+    assert torch.equal(v16, v32), "the same local scenes survive"
+    assert o16.shape == o32.shape and o16.numel() - 1 >= 10
+
+    def members(idx, sid):
+        s = sid[idx[:, 0]]
+        return set(zip(s.tolist(), idx[:, 1].tolist()))
+    m32_, m16_ = members(i32.cpu(), v32.cpu()), members(i16.cpu(), v16.cpu())
+    frac = len(m32_ ^ m16_) / max(len(m32_), 1)
+    e_sc = (r16["clt_scores"].float() - r32["clt_scores"].float()).abs().max().item()
+    print("fp16 vs fp32 on the bench scene: %d proposals, %d of %d proposal rows differ (%.4f %%), clt_scores max |diff| %.2e" % (
+        o16.numel() - 1, len(m32_ ^ m16_), len(m32_), 100 * frac, e_sc))
+    assert frac <= FP16_MEMBERSHIP_BOUND and e_sc <= FP16_SCORE_TOL
+    # the whole forward from a HIP graph
+    cap = planned.measure_capacities(model, *_args(b), teacher=t).padded(1.25)
+    pf = planned.PlannedForward(model, cap, dtype=torch.float16)
+    want = pf(*_args(b), teacher=t)
+    _same_proposals(want, r16, 2e-3)
+    pf.capture(*_args(b), teacher=t)
+    for it in range(3):
+        rep = pf.finish(pf.replay())
+        for a_, w_ in zip(rep["proposals"], want["proposals"]):
+            assert torch.equal(a_, w_), it
+        assert torch.equal(rep["clt_scores"], want["clt_scores"]), it
+        assert bool(torch.isfinite(rep["clt_scores"].float()).all())
+        if it == 0:
+            torch.cuda.synchronize()

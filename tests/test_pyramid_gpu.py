@@ -199,15 +199,28 @@ def test_capacity_form_device_count():
     assert a["counts"][0] == len(coords)
 
 
-def test_box_beyond_44_key_bits_is_an_error_not_a_hang():
+def test_box_beyond_44_key_bits_falls_back_to_the_hash_pipeline():
     n = 1000
     rng = np.random.default_rng(2)
     coords = np.concatenate([rng.integers(0, 60000, (n, 1)), rng.integers(-32000, 32000, (n, 3))], 1).astype(np.int32)
     arena, P = _prepare(torch.from_numpy(coords).to(DEV), "sorted")
     counts = _view(arena, P.pyramid.counts, 5, torch.int32)
     assert counts[0] == -1
+    # the coordinate manager retries such a lineage through the hash-table pipeline (same arena, same layout): wide scenes
+    # and large batch indices keep working, as they did before the sorted pipeline became the default
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(DEV), prepare="sorted")
+    assert cm.num_rows(1) == len(np.unique(coords, axis=0))
+    plain = ME.CoordinateManager(torch.from_numpy(coords).to(DEV), prepare="plain")
+    sv = cm.sorted()
+    a = sv.pyramid.coordinates(1).cpu().numpy()
+    assert {tuple(r) for r in a.tolist()} == {tuple(r) for r in plain.coordinates(1).cpu().numpy().tolist()}
+    for s_ in (2, 4, 8, 16):
+        assert sv.pyramid.n[sv.pyramid.level_index(s_)] == plain.num_rows(s_)
+    # ... and a coordinate outside the 16-bit range is still an error
+    bad = coords.copy()
+    bad[0, 1] = 40000
     with pytest.raises(ValueError):
-        ME.CoordinateManager(torch.from_numpy(coords).to(DEV), prepare="sorted").num_rows(1)
+        ME.CoordinateManager(torch.from_numpy(bad).to(DEV), prepare="sorted").num_rows(1)
 
 
 def test_c4_sized_scene():
