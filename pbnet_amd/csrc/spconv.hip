@@ -31,8 +31,6 @@
 namespace pbn {
 namespace {
 
-constexpr int CONV_TPB = 256;
-
 constexpr int CGMAX = 4;  // channel chunks (steps) per group
 
 // (Round 3: the quad-coalesced row gathers of spconv_wave.hip -- lane 4 r + c fetches chunk c of row r, operand order
@@ -70,11 +68,12 @@ __device__ unsigned g_conv_timing[4 * 64 * 8 + 8];
 // complete in issue order, so "the DMA of this group has landed" and "chunk c has landed" are fixed counts of the
 // loads issued after them -- the barrier never waits for the gathers behind the DMA, an MFMA never waits for a DMA.
 // (hipcc's own wait-count insertion is conservative across the loop's branches and drains the queue.)
-template <typename T, int NF, int NT, int RING>
-__global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
+template <typename T, int NF, int NT, int RING, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
     static_assert(Tr<T>::ELEMS * sizeof(T) == 16, "one gather vector is 16 bytes");
+    constexpr int CONV_TPB = NW * 64;                    // NW = 8 (round 4): one weight ring feeds 8 waves = twice the rows per weight byte
     constexpr int RW = NF * 16;
-    constexpr int TM = 4 * RW;
+    constexpr int TM = NW * RW;
     constexpr int NFRAG = TM / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = a.K;
@@ -95,9 +94,9 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
     const int row0 = xcd_tile(blockIdx.x, gridDim.x) * TM;
 #ifdef PBN_CONV_TIMING
-    __shared__ unsigned s_time[4 * 64 * 8];
+    __shared__ unsigned s_time[NW * 64 * 8];
     const bool timed_ = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0;
-    if (timed_) for (int e = tid; e < 4 * 64 * 8; e += CONV_TPB) s_time[e] = 0u;
+    if (timed_) for (int e = tid; e < NW * 64 * 8; e += CONV_TPB) s_time[e] = 0u;
 #endif
     if (row0 >= n) return;
     const int tile0 = blockIdx.y * NT;
@@ -242,8 +241,8 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     {                                                                                                                 \
         const unsigned gbase_ = ((unsigned)(GI) * (CG) * a.ntiles_total + tile0) * 1024u;                             \
         const unsigned wv_ = ((MORE) && !(a.dbg & 8)) ? w_lane : OOB;                                                 \
-        _Pragma("unroll") for (int i = 0; i < ((CG) * NT + 3) / 4; ++i) {                                             \
-            const int p_ = min(wave + 4 * i, (CG) * NT - 1);                                                          \
+        _Pragma("unroll") for (int i = 0; i < ((CG) * NT + NW - 1) / NW; ++i) {                                       \
+            const int p_ = min(wave + NW * i, (CG) * NT - 1);                                                         \
             const int c_ = p_ / NT, t_ = p_ - c_ * NT;                                                                \
             PBN_TIMING_SKIP_DMA;                                                                                      \
             unsigned keep_;                                                                                           \
@@ -263,7 +262,7 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
     //   chunk c  : loads behind x[c](g) = x[c+1..](g), DMA(g + DEPTH), x[..c-1](g + 1) = (CG-1)*NF + PW
 #define PBN_GROUP(POS, CG)                                                                                            \
     {                                                                                                                 \
-        constexpr int PW_ = ((CG) * NT + 3) / 4;                                                                      \
+        constexpr int PW_ = ((CG) * NT + NW - 1) / NW;                                                                \
         PBN_STAMP(POS, 0);                                                                                            \
         asm volatile("s_waitcnt vmcnt(%0)" : : "n"((CG) * NF + (DEPTH - 1) * (PW_ + (CG) * NF)) : "memory");          \
         PBN_STAMP(POS, 1);                                                                                            \
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(CONV_TPB) void k_spconv(const ConvArgs a) {
 #ifdef PBN_CONV_TIMING
     __syncthreads();
     if (timed_) {
-        for (int e = tid; e < 4 * 64 * 8; e += CONV_TPB) g_conv_timing[e] = s_time[e];
+        for (int e = tid; e < 4 * 64 * 8; e += CONV_TPB) g_conv_timing[e] = s_time[e];   // the first four waves
         if (tid == 0) { g_conv_timing[4 * 64 * 8] = (unsigned)(ng - g_lo); g_conv_timing[4 * 64 * 8 + 1] = (unsigned)cg; }
     }
 #endif
@@ -426,9 +425,10 @@ __global__ __launch_bounds__(256) void k_spconv_reduce(const ConvArgs a) {
     store4<T>(reinterpret_cast<T*>(a.out) + (size_t)orow * a.ld_out + c0, v);
 }
 
-template <typename T, int NF, int NT, int RING>
+template <typename T, int NF, int NT, int RING, int NW = 4>
 int launch_ring(ConvArgs a, int ngroups, float* workspace, size_t workspace_bytes, hipStream_t stream) {
-    constexpr int TM = 64 * NF;
+    constexpr int TM = 16 * NW * NF;
+    constexpr int CONV_TPB = NW * 64;
     const int KS = a.K | 1;
     // steps per barrier group: the largest divisor <= 4 of the steps per offset (1 when offsets are narrower than a step)
     a.cg = 1;
@@ -441,7 +441,7 @@ int launch_ring(ConvArgs a, int ngroups, float* workspace, size_t workspace_byte
     const size_t lds = (size_t)RING * a.cg * NT * 1024 +
                        sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 3 * ((size_t)n_groups + 4) + 2 * NT * 16 + 4);
     if (lds > 160 * 1024) return PBN_ERR_UNSUPPORTED;
-    auto kern = k_spconv<T, NF, NT, RING>;
+    auto kern = k_spconv<T, NF, NT, RING, NW>;
     if (lds > 64 * 1024)
         PBN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tiles = cdiv(a.n_out, TM);
@@ -481,6 +481,17 @@ template <typename T, int NF, int NT>
 int launch_one(const ConvArgs& a, int ngroups, float* ws, size_t wsb, hipStream_t stream) {
     // RING = 3 (two weight tiles in flight): experiment switch PBN_CONV_RING=3 for the small levels (< 8k rows)
     static const int ring_env = getenv("PBN_CONV_RING") ? atoi(getenv("PBN_CONV_RING")) : 2;
+    // 8-wave workgroups (256 rows at NF = 2 share one weight ring: half the weight DMA per row).  Measured round 4
+    // (scripts/probe_halo.py, PBN_CONV_WAVES8=1): SLOWER everywhere -- L0 96->96 89 -> 106 us, L1 96->96 38 -> 56, L1 32->32 17 ->
+    // 26: the ring's barrier then spans 8 waves and the weight stream was not what bound the kernel.  Off by default.
+    // PBN_CONV_WAVES8: 0 never (default), 1 always, else the row count from which they are used
+    static const long long w8_env = getenv("PBN_CONV_WAVES8") ? atoll(getenv("PBN_CONV_WAVES8")) : 0;
+    if constexpr (NF == 2) {
+        if (a.K <= 32 && (w8_env == 1 || (w8_env > 1 && a.n_out >= w8_env))) {
+            const int rc = launch_ring<T, NF, NT, 2, 8>(a, ngroups, ws, wsb, stream);
+            if (rc != PBN_ERR_UNSUPPORTED) return rc;
+        }
+    }
     if constexpr (NF == 1) {
         if (ring_env == 3 && a.n_out < 8192) {
             const int rc = launch_ring<T, NF, NT, 3>(a, ngroups, ws, wsb, stream);

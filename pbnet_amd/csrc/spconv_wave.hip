@@ -519,6 +519,10 @@ int pick_cfg(const ConvArgs& a) {
     // stem-like layers (a 16/32-byte input row, K = 125): 32 rows x 32 channels per workgroup measured best at every size
     // (146 k rows: 44.8 us against 68.1 for 64 rows and 72.6 for the workgroup-tile kernel)
     if (a.vpo <= 2 && a.K >= 64 && ntt % 2 == 0) return 1202;
+    // the k = 5 stems of the local-scene networks (32 / 64-byte... 64 / 128-byte input rows, 125 offsets, 58 k rows): the same
+    // shape wins there (round 4, scripts/probe_halo.py: 146 k rows 32->32 152 -> 90 us, 64->32 179 -> 156 against the
+    // workgroup-tile kernel, whose 125-column rulebook tile leaves it two workgroups per CU)
+    if (a.vpo <= 8 && a.K >= 64 && ntt % 2 == 0) return 1202;
     int best = 0;
     long long best_wgs = -1;
     for (int cfg : {1404, 1204, 1402, 1202, 1401, 1201}) {
@@ -583,7 +587,7 @@ bool wave_family_wanted(const ConvArgs& a, int dtype) {
     if (a.K > 128) return false;
     if (fam == 0) return false;
     if (fam == 1) return true;
-    if (a.vpo <= 2 && a.K >= 64 && !a.row_perm) return true;   // the k = 5 stem: rulebook-bound, no weight reuse to speak of
+    if (a.vpo <= 8 && a.K >= 64 && !a.row_perm) return true;   // the k = 5 stems: rulebook-bound, no weight reuse to speak of
     const double elems_per_step = 4.0 * (dtype == PBN_F32 ? 4.0 : 8.0);
     const double dense = (double)a.n_out * a.n_steps * elems_per_step * a.ntiles_total * 16.0;
     return a.n_out < max_rows && dense <= max_macs;
