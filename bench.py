@@ -259,6 +259,7 @@ class ConvProbe(object):
 
     def _unet_sink(self, plan, rows, cm, esz, op_ms):
         pair_cache = {}
+        second = {i: c for i, c, _ in plan.get("folded_io", [])}     # op index -> C_in of a folded 1x1 shortcut (second source)
         for i in range(plan["n_ops"]):
             op = plan["ops"][i]
             key = (op.map_kind, op.level_in, op.level_out)
@@ -274,6 +275,11 @@ class ConvProbe(object):
             if op.res_buf >= 0:
                 r1 += v_out * cout_p * esz
             flops = 2 * pairs * cin_t * cout_t
+            if i in second:              # the folded shortcut: its input slab and its weights are read as well, nothing more is written
+                extra = (v_out * second[i] + second[i] * cout_t) * esz
+                nbytes += extra
+                r1 += extra
+                flops += 2 * v_out * second[i] * cout_t
             self.nbytes += nbytes
             self.nbytes_r1 += r1
             self.flops += flops

@@ -168,6 +168,22 @@ int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, const int32_t* 
                        int relu, void* out_feat, int ld_out, int dtype, int rows_per_wave, void* workspace,
                        size_t workspace_bytes, pbn_stream_t stream);
 
+/* The same convolution with a SECOND SOURCE folded into its reduction (round 4): a BasicBlock's 1x1 shortcut
+ * (network/Mink.py:77-87: `downsample` = 1x1 convolution + BatchNorm on the block input, added before the last ReLU)
+ * becomes extra reduction steps of the block's second convolution --
+ *     out[o, c] = act( (sum_k sum_ci in[nbr[o,k], ci] W[k, ci, c] + sum_cj in2[o, cj] W2[cj, c]) * scale[c] + shift[c] + ... )
+ * -- one launch and no residual slab instead of two launches.  w_packed holds the steps of the map followed by the steps of
+ * the second source: vecs_second / 4 of them, zero-padded by the caller to a whole number of barrier groups of the first
+ * source (largest divisor <= 4 of vecs_per_offset / 4), n_steps = the total.  BatchNorm scales of the two branches differ:
+ * the caller folds them into the packed weights (scale NULL) and passes the summed shifts.  Both sources: vectors per row a
+ * multiple of 4; in2 has at least n_out rows (row o pairs with output row o). */
+int pbn_spconv_forward_dual(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
+                            const int32_t* n_out_dev, int n_out, const void* w_packed, int vecs_per_offset, int n_steps,
+                            int cout_padded, const float* scale, const float* shift, const void* residual, int ld_res,
+                            int relu, void* out_feat, int ld_out, int dtype, int rows_per_wave, void* workspace,
+                            size_t workspace_bytes, const void* in2_feat, int ld_in2, int n_in2, int vecs_second,
+                            pbn_stream_t stream);
+
 /* out[i, :] = in[idx[i], :] on 16-byte multiples (voxel -> point gathers, network/PBNet.py:130-134,250); a negative
  * index gives a zero row (padding slots of the compacted weight-gradient operands). */
 int pbn_gather_rows(const void* in, int ld_in_bytes, const int64_t* idx, int n, int row_bytes, void* out,
@@ -553,7 +569,9 @@ int pbn_morton_keys(const int32_t* coords, const int32_t* n_dev, int n_max, int6
 typedef struct {
     int32_t map_kind, level_in, level_out;
     int32_t in_buf, in_col, res_buf, res_col, out_buf, out_col;
-    int32_t vpo, n_steps, cout_p, relu, _pad;
+    int32_t vpo, n_steps, cout_p, relu;
+    int32_t in2_buf;            /* >= 0: second source of pbn_spconv_forward_dual (a folded 1x1 shortcut), else -1 */
+    int32_t in2_col, vpo2;
     const void* w;
     const float* scale;
     const float* shift;

@@ -239,6 +239,25 @@ def spconv_forward(feats, nbr, n_out, packed, scale=None, shift=None, residual=N
     return out
 
 
+def spconv_forward_dual(feats, nbr, n_out, feats2, packed, vpo2, shift=None, scale=None, relu=False, out=None, rows_per_wave=0):
+    """pbn_spconv_forward_dual: the convolution over `nbr` plus a 1x1 over `feats2` (row o with output row o) in one reduction.
+    packed = (w [steps of the map | steps of the second source (| zero padding)], vpo, n_steps_total, cout_p)."""
+    w, vpo, n_steps, cout_p = packed
+    dtype = feats.dtype
+    assert feats.stride(1) == 1 and feats2.stride(1) == 1 and feats2.dtype == dtype
+    if out is None:
+        out = torch.empty(n_out, cout_p, dtype=dtype, device=feats.device)
+    ws = _workspace(feats.device)
+    rc = N.lib().pbn_spconv_forward_dual(
+        N.c_vp(feats.data_ptr()), feats.stride(0), int(feats.shape[0]), N.c_vp(nbr.data_ptr()), int(nbr.shape[1]), None, int(n_out),
+        N.c_vp(w.data_ptr()), vpo, n_steps, cout_p, None if scale is None else N.c_vp(scale.data_ptr()),
+        None if shift is None else N.c_vp(shift.data_ptr()), None, 0, int(bool(relu)), N.c_vp(out.data_ptr()), out.stride(0),
+        _DT[dtype], int(rows_per_wave), N.c_vp(ws.data_ptr()), ws.numel(), N.c_vp(feats2.data_ptr()), feats2.stride(0),
+        int(feats2.shape[0]), int(vpo2), N.current_stream())
+    N.check(rc, "pbn_spconv_forward_dual")
+    return out
+
+
 class HaloTable(object):
     """Halo tables of one kernel map (pbn_halo_build): per tile of 128 output rows the distinct input rows, the map as
     16-bit slots into that list and the per-offset fragment masks (csrc/spconv_halo.hip)."""

@@ -56,7 +56,8 @@ class UnetOp(ctypes.Structure):
     _fields_ = [("map_kind", c_i32), ("level_in", c_i32), ("level_out", c_i32),
                 ("in_buf", c_i32), ("in_col", c_i32), ("res_buf", c_i32), ("res_col", c_i32), ("out_buf", c_i32),
                 ("out_col", c_i32), ("vpo", c_i32), ("n_steps", c_i32), ("cout_p", c_i32), ("relu", c_i32),
-                ("_pad", c_i32), ("w", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p)]
+                ("in2_buf", c_i32), ("in2_col", c_i32), ("vpo2", c_i32),
+                ("w", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p)]
 
 
 class UnetBuf(ctypes.Structure):
@@ -110,6 +111,8 @@ SIGNATURES = {
     "pbn_up_table": (c_int, [c_i32p, c_i32p, c_i32p, c_int, c_i32p, c_vp]),
     "pbn_spconv_forward": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_i32p, c_int, c_vp, c_int, c_int, c_int,
                                    c_f32p, c_f32p, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp]),
+    "pbn_spconv_forward_dual": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_int, c_vp, c_int, c_int, c_int, c_f32p, c_f32p,
+                                        c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp, c_int, c_int, c_int, c_vp]),
     "pbn_halo_bytes": (c_size, [c_int, c_int, c_int, ctypes.POINTER(HaloLayout)]),
     "pbn_halo_build": (c_int, [ctypes.POINTER(HaloJob), c_int, c_vp]),
     "pbn_spconv_forward_halo": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_int, c_vp, c_int, c_int, c_int, c_f32p,

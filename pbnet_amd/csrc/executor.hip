@@ -248,10 +248,20 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
         void* out = base(o.out_buf) + (size_t)o.out_col * es;
         const void* res = o.res_buf >= 0 ? base(o.res_buf) + (size_t)o.res_col * es : nullptr;
         if (events) PBN_HIP_CHECK(hipEventRecord(events[2 * i], (hipStream_t)stream));
-        const int rc = pbn_spconv_forward(in, ld(o.in_buf), n_rows[o.level_in], nbr, K, nullptr,
-                                          n_rows_dev ? n_rows_dev + o.level_out : nullptr, n_rows[o.level_out], o.w, o.vpo,
-                                          o.n_steps, o.cout_p, o.scale, o.shift, res, o.res_buf >= 0 ? ld(o.res_buf) : 0,
-                                          o.relu, out, ld(o.out_buf), dtype, 0, splitk_ws, splitk_bytes, stream);
+        int rc;
+        if (o.in2_buf >= 0) {           // a BasicBlock's 1x1 shortcut folded into this convolution's reduction
+            if (o.in2_buf >= n_bufs) return PBN_ERR_ARG;
+            const void* in2 = base(o.in2_buf) + (size_t)o.in2_col * es;
+            rc = pbn_spconv_forward_dual(in, ld(o.in_buf), n_rows[o.level_in], nbr, K,
+                                         n_rows_dev ? n_rows_dev + o.level_out : nullptr, n_rows[o.level_out], o.w, o.vpo,
+                                         o.n_steps, o.cout_p, o.scale, o.shift, res, o.res_buf >= 0 ? ld(o.res_buf) : 0, o.relu,
+                                         out, ld(o.out_buf), dtype, 0, splitk_ws, splitk_bytes, in2, ld(o.in2_buf),
+                                         n_rows[o.level_out], o.vpo2, stream);
+        } else
+            rc = pbn_spconv_forward(in, ld(o.in_buf), n_rows[o.level_in], nbr, K, nullptr,
+                                    n_rows_dev ? n_rows_dev + o.level_out : nullptr, n_rows[o.level_out], o.w, o.vpo,
+                                    o.n_steps, o.cout_p, o.scale, o.shift, res, o.res_buf >= 0 ? ld(o.res_buf) : 0,
+                                    o.relu, out, ld(o.out_buf), dtype, 0, splitk_ws, splitk_bytes, stream);
         if (rc != PBN_OK) return rc;
         if (events) PBN_HIP_CHECK(hipEventRecord(events[2 * i + 1], (hipStream_t)stream));
     }

@@ -83,8 +83,8 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
     constexpr int DEPTH = RING - 1;                                                 // weight tiles in flight ahead
     u32x4* s_w = reinterpret_cast<u32x4*>(smem);                                    // RING slots x cg * NT * 64 vectors
     int* s_nbr = reinterpret_cast<int*>(smem + (size_t)RING * cg * NT * 1024);      // TM * KS
-    int* s_valid = s_nbr + TM * KS;                                                 // K fragment masks
-    int* s_grp = s_valid + ((K + 3) & ~3);                                          // n_groups + 4 (entry n_groups = count)
+    int* s_valid = s_nbr + TM * KS;                                                 // K (+1: the second source) fragment masks
+    int* s_grp = s_valid + ((K + 4) & ~3);                                          // n_groups + 4 (entry n_groups = count)
     int* s_masks = s_grp + n_groups + 4;                                            // n_groups + 4 fragment masks
     int* s_gko = s_masks + n_groups + 4;                                            // n_groups + 4: offset | sub-group << 16
     float* s_ss = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(s_gko + n_groups + 4) + 15) & ~(uintptr_t)15);  // scale | shift
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
     if (row0 >= n) return;
     const int tile0 = blockIdx.y * NT;
 
-    for (int k = tid; k < K; k += CONV_TPB) s_valid[k] = 0;
+    for (int k = tid; k <= K; k += CONV_TPB) s_valid[k] = 0;
     // epilogue constants of this workgroup's NT*16 output channels -> LDS (read back after the reduction)
     if (a.ksplit == 1 && tid < NT * 32) {
         const int c = tile0 * 16 + (tid < NT * 16 ? tid : tid - NT * 16);
@@ -144,13 +144,23 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
     const int vpo = a.vpo;
     const bool wide = (vpo & 3) == 0;
     const int gpo = wide ? (vpo >> 2) / cg : 1;          // groups per offset (wide layers)
+    // second source (a.in2): its steps follow the K offsets as one more "offset" K whose neighbour is the row itself
+    const int n_main_groups = a.in2 ? a.n_main / cg : n_groups;
+    if (a.in2 && tid == 0) {
+        const int live = min(TM, n - row0);
+        s_valid[K] = (int)((live >= TM) ? ((NFRAG >= 32) ? 0xffffffffu : ((1u << NFRAG) - 1u)) : ((1u << ((live + 15) >> 4)) - 1u));
+    }
+    if (a.in2) __syncthreads();
     if (wave == 0) {
         int base = 0;
         for (int g0 = 0; g0 < n_groups; g0 += 64) {
             const int gi = g0 + lane;
             int fm = 0, ko = 0;
             if (gi < n_groups) {
-                if (wide) {
+                if (gi >= n_main_groups) {
+                    ko = K;
+                    fm = s_valid[K];
+                } else if (wide) {
                     ko = gi / gpo;
                     fm = s_valid[ko];
                 } else {
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
                 const int pos = base + __popcll(m & ((1ULL << lane) - 1ULL));
                 s_grp[pos] = gi;
                 s_masks[pos] = fm | ((a.dbg & 1) ? 0xffff : 0);
-                s_gko[pos] = ko | ((gi - ko * gpo) << 16);
+                s_gko[pos] = ko | ((gi >= n_main_groups ? gi - n_main_groups : gi - ko * gpo) << 16);
             }
             base += __popcll(m);
         }
@@ -199,6 +209,16 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
     const i32x4 rs_w = {(int)(unsigned)w_addr, (int)(unsigned)(w_addr >> 32), (int)a.w_bytes, 0x00020000};
     constexpr unsigned OOB = 0x80000000u;  // >= num_records: the bounds check turns the load into zeros
     const unsigned ld_bytes = (unsigned)a.ld_in * (unsigned)sizeof(T);
+    const unsigned long long in2_addr = (unsigned long long)a.in2;
+    const i32x4 rs_in2 = {(int)(unsigned)in2_addr, (int)(unsigned)(in2_addr >> 32), (int)a.in2_bytes, 0x00020000};
+    const unsigned ld2_bytes = (unsigned)a.ld_in2 * (unsigned)sizeof(T);
+    bool nx2_ = false;                     // the group whose rows are being fetched reads the second source
+    int nxv_ = 4;                          // ... and this many of its chunks exist
+    auto pick_rs = [&](bool second) -> i32x4 {          // wave-uniform choice, made provably scalar for the "s" constraint
+        const bool s2 = __builtin_amdgcn_readfirstlane((int)second) != 0;
+        return i32x4{__builtin_amdgcn_readfirstlane(s2 ? rs_in2[0] : rs_in[0]), __builtin_amdgcn_readfirstlane(s2 ? rs_in2[1] : rs_in[1]),
+                     __builtin_amdgcn_readfirstlane(s2 ? rs_in2[2] : rs_in[2]), 0x00020000};
+    };
     const int vshift = (vpo == 2) ? 1 : 0;
     const unsigned w_step_bytes = (unsigned)a.ntiles_total * 1024u;   // one step, all channel tiles
     const unsigned w_lane = (unsigned)lane * 16u;
@@ -214,18 +234,24 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
             const int pk_ = __builtin_amdgcn_readfirstlane(s_gko[POS]);                                               \
             ko_ = pk_ & 0xffff; cv_ = (pk_ >> 16) * (CG) * 4 + g;                                                     \
         } else { const int v_ = (GI) * 4 + g; ko_ = v_ >> vshift; cv_ = v_ & (vpo - 1); }                             \
+        nx2_ = a.in2 != nullptr && (MORE) && ko_ == K;                                                                \
+        /* chunks of the group that exist in the second source's rows (its steps are zero-padded to whole groups: a   */ \
+        /* padded chunk must not gather what lies behind the row -- 0 x NaN of an uninitialised neighbour is NaN)      */ \
+        nxv_ = nx2_ ? (a.vpo2 >> 2) - (__builtin_amdgcn_readfirstlane(s_gko[POS]) >> 16) * (CG) : (CG);               \
+        const unsigned ldb_ = nx2_ ? ld2_bytes : ld_bytes;                                                            \
         _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                              \
             const int r_ = wave * RW + f * 16 + rl;                                                                   \
-            const int src_ = ((MORE) && ko_ < K) ? s_nbr[r_ * KS + ko_] : -1;                                         \
-            VOFF[f] = (src_ >= 0 && !(a.dbg & 4)) ? (unsigned)src_ * ld_bytes + (unsigned)cv_ * 16u : OOB;            \
+            int src_ = ((MORE) && ko_ < K) ? s_nbr[r_ * KS + ko_] : -1;                                               \
+            if (nx2_) src_ = row0 + r_ < n ? row0 + r_ : -1;                                                          \
+            VOFF[f] = (src_ >= 0 && !(a.dbg & 4)) ? (unsigned)src_ * ldb_ + (unsigned)cv_ * 16u : OOB;                \
         }                                                                                                             \
     }
     // refill chunk C's operand registers in place ("+v": the load lands in the register the MFMAs just read)
-#define PBN_LOAD_X(VOFF, C)                                                                                           \
+#define PBN_LOAD_X(VOFF, C, RS)                                                                                       \
     {                                                                                                                 \
         _Pragma("unroll") for (int f = 0; f < NF; ++f)                                                                \
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen"                                                   \
-                         : "+v"(x[C][f]) : "v"(VOFF[f]), "s"(rs_in), "s"((C) * 64));                                  \
+                         : "+v"(x[C][f]) : "v"((C) < nxv_ ? VOFF[f] : OOB), "s"(RS), "s"((C) * 64));                  \
     }
     // wait until at most N vector-memory loads are outstanding; names chunk C's registers so that their readers
     // are ordered behind the wait
@@ -282,6 +308,7 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
             fcur = more_ ? fnext_ : 0u;                                                                               \
             PBN_GROUP_ROWS((POS) + 1, gnext_, more_, vnext_, CG);                                                     \
         }                                                                                                             \
+        const i32x4 rsn_ = pick_rs(nx2_);              /* wave-uniform: the resource of the group being fetched */   \
         PBN_STAMP(POS, 3);                                                                                            \
         /* the asm statements that define x[][] stay on the straight-line path: inside a branch the compiler would */ \
         /* merge them through register copies, i.e. read registers whose loads are still in flight                 */ \
@@ -297,7 +324,7 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
                     _Pragma("unroll") for (int f = 0; f < NF; ++f) mfma_step<T>(wf_[c & 1][t], x[c][f], acc[f][t]);   \
                 }                                                                                                     \
             }                                                                                                         \
-            PBN_LOAD_X(vnext_, c);                                                                                    \
+            PBN_LOAD_X(vnext_, c, rsn_);                                                                              \
         }                                                                                                             \
         PBN_STAMP(POS, 6);                                                                                            \
     }
@@ -316,7 +343,8 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
             PBN_DMA_W(gj_, g_lo + j < ng, lds_w + (unsigned)j * slot_bytes, CG);                                      \
             const int g0_ = __builtin_amdgcn_readfirstlane(s_grp[g_lo]);                                              \
             PBN_GROUP_ROWS(g_lo, g0_, j == DEPTH - 1, v0_, CG);                                                       \
-            _Pragma("unroll") for (int c = 0; c < (CG); ++c) { PBN_LOAD_X(v0_, c); }                                  \
+            const i32x4 rs0_ = pick_rs(nx2_);                                                                         \
+            _Pragma("unroll") for (int c = 0; c < (CG); ++c) { PBN_LOAD_X(v0_, c, rs0_); }                            \
         }                                                                                                             \
         for (int pos = g_lo; pos < ng; ++pos) PBN_GROUP(pos, CG);                                                     \
         /* drain: the loads issued for the (non-existent) group past the end still target these registers */         \
@@ -439,7 +467,7 @@ int launch_ring(ConvArgs a, int ngroups, float* workspace, size_t workspace_byte
     }
     const int n_groups = a.n_steps / a.cg;
     const size_t lds = (size_t)RING * a.cg * NT * 1024 +
-                       sizeof(int) * ((size_t)TM * KS + ((a.K + 3) & ~3) + 3 * ((size_t)n_groups + 4) + 2 * NT * 16 + 4);
+                       sizeof(int) * ((size_t)TM * KS + ((a.K + 4) & ~3) + 3 * ((size_t)n_groups + 4) + 2 * NT * 16 + 4);
     if (lds > 160 * 1024) return PBN_ERR_UNSUPPORTED;
     auto kern = k_spconv<T, NF, NT, RING, NW>;
     if (lds > 64 * 1024)
@@ -534,23 +562,32 @@ __global__ __launch_bounds__(256) void k_gather_rows(const uint4* __restrict__ i
 
 using namespace pbn;
 
-extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
-                                  const int32_t* row_perm, const int32_t* n_out_dev, int n_out, const void* w_packed,
-                                  int vecs_per_offset, int n_steps, int cout_padded, const float* scale,
-                                  const float* shift, const void* residual, int ld_res, int relu, void* out_feat,
-                                  int ld_out, int dtype, int rows_per_wave, void* workspace, size_t workspace_bytes,
-                                  pbn_stream_t stream_) {
+static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
+                               const int32_t* row_perm, const int32_t* n_out_dev, int n_out, const void* w_packed,
+                               int vecs_per_offset, int n_steps, int cout_padded, const float* scale,
+                               const float* shift, const void* residual, int ld_res, int relu, void* out_feat,
+                               int ld_out, int dtype, int rows_per_wave, void* workspace, size_t workspace_bytes,
+                               pbn_stream_t stream_, const void* in2_feat, int ld_in2, int n_in2, int vecs_second) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_out < 0 || n_in < 0 || n_offsets < 1 || vecs_per_offset < 1 || n_steps < 1 || cout_padded < 16 || (cout_padded & 15))
         return PBN_ERR_ARG;
     if (!(vecs_per_offset == 1 || vecs_per_offset == 2 || (vecs_per_offset & 3) == 0)) return PBN_ERR_ARG;
-    if (n_steps != (n_offsets * vecs_per_offset + 3) / 4) return PBN_ERR_ARG;
+    const int n_main = (n_offsets * vecs_per_offset + 3) / 4;
+    if (in2_feat) {
+        // second source: wide rows on both sides, a real map, no processing order; its steps follow the map's (padded by the
+        // caller to whole barrier groups of the first source: zero weights behind the real channels)
+        if ((vecs_per_offset & 3) || vecs_second < 4 || (vecs_second & 3) || !nbr || row_perm || n_in2 < n_out) return PBN_ERR_ARG;
+        if (n_steps < n_main + (vecs_second >> 2) || n_steps > n_main + (vecs_second >> 2) + 3) return PBN_ERR_ARG;
+    } else if (n_steps != n_main) return PBN_ERR_ARG;
     if (!nbr && n_offsets != 1) return PBN_ERR_ARG;
     if (n_out == 0) return PBN_OK;
     if (!in_feat || !w_packed || !out_feat) return PBN_ERR_ARG;
     const int esz = dtype == PBN_F32 ? 4 : 2;
     if ((ld_in * esz) % 16 || (ld_out * esz) % 8 || (residual && (ld_res * esz) % 8)) return PBN_ERR_ARG;
     if (((uintptr_t)in_feat | (uintptr_t)w_packed) & 15) return PBN_ERR_ARG;
+    if (in2_feat && ((ld_in2 * esz) % 16 || ((uintptr_t)in2_feat & 15))) return PBN_ERR_ARG;
+    const unsigned long long in2_extent = in2_feat ? (unsigned long long)n_in2 * (unsigned long long)ld_in2 * (unsigned long long)esz : 0ull;
+    if (in2_extent >= 0x80000000ull) return PBN_ERR_RANGE;
     // gathers address the slab with 32-bit byte offsets through a buffer resource (k_spconv): a slab or weight block of
     // 2 GiB or more cannot be addressed -- refuse it instead of silently gathering zeros past the limit
     const unsigned long long in_extent = (unsigned long long)n_in * (unsigned long long)ld_in * (unsigned long long)esz;
@@ -564,6 +601,7 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, cons
     a.K = n_offsets; a.vpo = vecs_per_offset; a.n_steps = n_steps; a.ntiles_total = cout_padded / 16; a.n_out = n_out;
     a.relu = relu;
     a.ksplit = 1; a.partial = nullptr; a.n_out_pad = 0; a.cg = 1; a.wmajor = 0;
+    a.in2 = in2_feat; a.ld_in2 = ld_in2; a.vpo2 = vecs_second; a.n_main = n_main; a.in2_bytes = (unsigned)in2_extent;
     static const int dbg_env = getenv("PBN_CONV_DBG") ? atoi(getenv("PBN_CONV_DBG")) : 0;
     a.dbg = dbg_env;
     // coarse levels (and whatever PBN_CONV_FAMILY selects): the wave-autonomous family of spconv_wave.hip -- K split over
@@ -583,6 +621,29 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, cons
         case PBN_F16: return launch_t<__half>(a, rows_per_wave, ws, workspace_bytes, stream);
         default: return PBN_ERR_ARG;
     }
+}
+
+extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
+                                  const int32_t* row_perm, const int32_t* n_out_dev, int n_out, const void* w_packed,
+                                  int vecs_per_offset, int n_steps, int cout_padded, const float* scale,
+                                  const float* shift, const void* residual, int ld_res, int relu, void* out_feat,
+                                  int ld_out, int dtype, int rows_per_wave, void* workspace, size_t workspace_bytes,
+                                  pbn_stream_t stream_) {
+    return spconv_forward_impl(in_feat, ld_in, n_in, nbr, n_offsets, row_perm, n_out_dev, n_out, w_packed, vecs_per_offset,
+                               n_steps, cout_padded, scale, shift, residual, ld_res, relu, out_feat, ld_out, dtype,
+                               rows_per_wave, workspace, workspace_bytes, stream_, nullptr, 0, 0, 0);
+}
+
+extern "C" int pbn_spconv_forward_dual(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
+                                       const int32_t* n_out_dev, int n_out, const void* w_packed, int vecs_per_offset,
+                                       int n_steps, int cout_padded, const float* scale, const float* shift,
+                                       const void* residual, int ld_res, int relu, void* out_feat, int ld_out, int dtype,
+                                       int rows_per_wave, void* workspace, size_t workspace_bytes, const void* in2_feat,
+                                       int ld_in2, int n_in2, int vecs_second, pbn_stream_t stream_) {
+    if (!in2_feat) return PBN_ERR_ARG;
+    return spconv_forward_impl(in_feat, ld_in, n_in, nbr, n_offsets, nullptr, n_out_dev, n_out, w_packed, vecs_per_offset,
+                               n_steps, cout_padded, scale, shift, residual, ld_res, relu, out_feat, ld_out, dtype,
+                               rows_per_wave, workspace, workspace_bytes, stream_, in2_feat, ld_in2, n_in2, vecs_second);
 }
 
 #ifdef PBN_CONV_TIMING

@@ -33,6 +33,11 @@ struct ConvArgs {
     int cg;              // steps per barrier group (1..4)
     int wmajor;          // wave family: weight-major block order (spconv_wave.hip map_block)
     int dbg;             // ablation switches for scripts/probe_conv_ablate.py (PBN_CONV_DBG); 0 in production
+    // second source (round 4: a BasicBlock's 1x1 shortcut folded into its second convolution, Mink.py:77-87): reduction steps
+    // n_main .. n_steps-1 read row o of `in2` (identity map), vpo2 vectors per row; null = none
+    const void* in2;
+    int ld_in2, vpo2, n_main;
+    unsigned in2_bytes;
 };
 
 namespace {

@@ -168,6 +168,11 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     const i32x4 rs_in = {(int)(unsigned)in_addr, (int)(unsigned)(in_addr >> 32), (int)a.in_bytes, 0x00020000};
     const i32x4 rs_w = {(int)(unsigned)w_addr, (int)(unsigned)(w_addr >> 32), (int)a.w_bytes, 0x00020000};
     const unsigned ld_bytes = (unsigned)a.ld_in * (unsigned)sizeof(T);
+    // second source (a BasicBlock's 1x1 shortcut folded into its second convolution): steps n_main.. read row o of in2
+    const unsigned long long in2_addr = (unsigned long long)a.in2;
+    const i32x4 rs_in2 = {(int)(unsigned)in2_addr, (int)(unsigned)(in2_addr >> 32), (int)a.in2_bytes, 0x00020000};
+    const unsigned ld2_bytes = (unsigned)a.ld_in2 * (unsigned)sizeof(T);
+    const int n_main = a.in2 ? a.n_main : a.n_steps;
     const unsigned w_lane = (unsigned)lane * 16u;
     const unsigned w_tile0 = (unsigned)tile0 * 1024u;
     const unsigned w_step_bytes = (unsigned)a.ntiles_total * 1024u;
@@ -261,7 +266,9 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
             bool ok = false;
             int ko = 0;
             if (s < a.n_steps) {
-                if (wide) {
+                if (s >= n_main) {
+                    ok = true;                   // the second source: every row has itself
+                } else if (wide) {
                     ko = s / spo;
                     ok = populated(ko);
                 } else {                      // a step spans 4 / vpo offsets; lane group g reads offset (4 s + g) >> vshift
@@ -297,14 +304,25 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     // offset -> out-of-range offset -> zeros)
     // The rulebook entries of a unit are read from LDS one unit AHEAD of its gathers (Idx travels in registers across one
     // iteration): the LDS round trips are off the issue path of the loads.
-    struct Idx { int src[NF]; unsigned cvb; };
+    struct Idx { int src[NF]; unsigned cvb; bool second; };
     auto fetch_idx = [&](int step) -> Idx {
         // lane group g reads vector v = 4 step + g of the flattened (offset, channel) axis: offset v / vpo, channel vector
         // v % vpo (float reciprocal: exact here); past the last offset or the last step -> the "-1" word -> zeros
         const int v = step * 4 + my_chunk;
+        Idx ix;
+        ix.second = __builtin_amdgcn_readfirstlane((int)(step >= n_main && step < n_steps)) != 0;   // wave-uniform
+        if (ix.second) {
+            const int cv = v - n_main * 4;
+            ix.cvb = (unsigned)cv * 16u;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int p = row0 + my_row + f * 16;
+                ix.src[f] = (p < n && cv < a.vpo2) ? p : -1;
+            }
+            return ix;
+        }
         const int ko = (int)(((float)v + 0.5f) * inv_vpo);
         const bool live = step < n_steps && ko < K;
-        Idx ix;
         ix.cvb = (unsigned)(v - ko * vpo) * 16u;
 #pragma unroll
         for (int f = 0; f < NF; ++f) ix.src[f] = *(live ? s_nbr + (my_row + f * 16) * KS + ko : s_none);
@@ -314,10 +332,14 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
 #ifdef PBN_CONV_TIMING
         if (a.dbg & 1) return;                                   // ablation: no row gathers
 #endif
+        const i32x4 rs = {__builtin_amdgcn_readfirstlane(ix.second ? rs_in2[0] : rs_in[0]),      // wave-uniform select
+                          __builtin_amdgcn_readfirstlane(ix.second ? rs_in2[1] : rs_in[1]),
+                          __builtin_amdgcn_readfirstlane(ix.second ? rs_in2[2] : rs_in[2]), 0x00020000};
+        const unsigned ldb = ix.second ? ld2_bytes : ld_bytes;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const unsigned voff = ix.src[f] >= 0 ? (unsigned)ix.src[f] * ld_bytes + ix.cvb : OOB;
-            buf_load_asm(st.x[f], rs_in, voff, 0u);
+            const unsigned voff = ix.src[f] >= 0 ? (unsigned)ix.src[f] * ldb + ix.cvb : OOB;
+            buf_load_asm(st.x[f], rs, voff, 0u);
         }
     };
     auto compute = [&](const Stage<NF, NT>& st) {

@@ -42,8 +42,19 @@ _UP = ("convtr4p16s2", "convtr5p8s2", "convtr6p4s2", "convtr7p2s2")
 _UP_BN = ("bntr4", "bntr5", "bntr6", "bntr7")
 
 
+def _group_steps(spo):
+    """Steps per barrier group of the workgroup-tile kernel: the largest divisor <= 4 of the steps per offset (spconv.hip)."""
+    for c in (4, 3, 2, 1):
+        if spo % c == 0:
+            return c
+    return 1
+
+
 class MinkUNet(nn.Module):
     FUSE_EVAL = True
+    # round 4: a BasicBlock's 1x1 shortcut (Mink.py:77-87) runs as extra reduction steps of the block's second convolution
+    # (pbn_spconv_forward_dual): 7 launches fewer per network and no residual slab.  PBNET_FOLD_SHORTCUT=0: separate launches.
+    FOLD_SHORTCUT = os.environ.get("PBNET_FOLD_SHORTCUT", "1") != "0"
     MORTON = os.environ.get("PBNET_MORTON", "1") != "0"   # fused path runs the lineage in Z-order (L2-local gathers)
     OP_TIMING_SINK = None   # callable(model, plan, rows, cm, esz, op_ms) installed by bench.py's roofline probe
 
@@ -159,7 +170,7 @@ class MinkUNet(nn.Module):
         Buffer 0 is the input slab; levels 0..4 are tensor strides 1..16."""
         from .. import _native as N
         P = self.PLANES
-        keep, ops, bufs, true_io = [], [], [(0, 0)], []
+        keep, ops, bufs, true_io, folded_io = [], [], [(0, 0)], [], []
         skip_c = (INIT_DIM, P[0], P[1], P[2])
         up_c = (P[7], P[6], P[5], P[4])
 
@@ -184,19 +195,63 @@ class MinkUNet(nn.Module):
             op.res_buf, op.res_col = res if res is not None else (-1, 0)
             op.out_buf, op.out_col = out
             op.vpo, op.n_steps, op.cout_p, op.relu = vpo, n_steps, cout_p, int(relu)
+            op.in2_buf, op.in2_col, op.vpo2 = -1, 0, 0
             op.w = w.data_ptr()
             op.scale = scale.data_ptr() if scale is not None else None
             op.shift = shift.data_ptr() if shift is not None else None
             ops.append(op)
             return out
 
+        def add_folded(blk, h, cur, l, out):
+            """relu(bn2(conv2(h)) + bn_d(conv_d(cur))) as ONE convolution over two sources: both BatchNorm scales go into the
+            weights (they differ per branch), the shifts add up, the 1x1 kernel becomes the reduction steps behind the map's."""
+            from ..MinkowskiEngine.conv import pack_weight
+            conv2, convd = blk.conv2, blk.downsample[0]
+            cout = int(conv2.kernel.shape[-1])
+            cout_p = (cout + 15) // 16 * 16
+            s2, b2 = self._fold(blk.norm2, cout_p)
+            sd, bd = self._fold(blk.downsample[1], cout_p)
+            k2 = conv2.kernel.detach().float() * s2[:cout]
+            kd = convd.kernel.detach().float()
+            kd = (kd if kd.dim() == 3 else kd.unsqueeze(0)) * sd[:cout]
+            w2, vpo, n_main, cp2 = pack_weight(k2, dtype)
+            wd, vpo2, n2, cpd = pack_weight(kd, dtype)
+            assert cp2 == cpd == cout_p and vpo % 4 == 0 and vpo2 % 4 == 0
+            cg = _group_steps(vpo // 4)
+            pad = (-n2) % cg                           # whole barrier groups of the first source: zero weights behind the real ones
+            parts = [w2, wd] + ([torch.zeros(pad, *wd.shape[1:], dtype=wd.dtype, device=wd.device)] if pad else [])
+            w = torch.cat(parts, 0).contiguous()
+            shift = (b2 + bd).contiguous()
+            keep.extend([w, shift])
+            true_io.append((int(conv2.kernel.shape[-2]) , cout))
+            folded_io.append((len(ops), int(kd.shape[-2]), cout))
+            if out is None:
+                out = (new_buf(l, cout_p), 0)
+            op = N.UnetOp()
+            op.map_kind, op.level_in, op.level_out = 1, l, l
+            op.in_buf, op.in_col = h
+            op.res_buf, op.res_col = -1, 0
+            op.out_buf, op.out_col = out
+            op.vpo, op.n_steps, op.cout_p, op.relu = vpo, n_main + n2 + pad, cout_p, 1
+            op.in2_buf, op.in2_col = cur
+            op.vpo2 = vpo2
+            op.w, op.scale, op.shift = w.data_ptr(), None, shift.data_ptr()
+            ops.append(op)
+            return out
+
         def stage(blocks, cur, l, out=None):
             for bi, blk in enumerate(blocks):
                 h = add(blk.conv1, blk.norm1, cur, 1, l, l)
+                last_out = out if bi == len(blocks) - 1 else None
+                if blk.downsample is not None and self.FOLD_SHORTCUT:
+                    from ..MinkowskiEngine.conv import _vpo
+                    if _vpo(int(blk.conv2.kernel.shape[-2]), dtype) % 4 == 0 and _vpo(int(blk.downsample[0].kernel.shape[-2]), dtype) % 4 == 0:
+                        cur = add_folded(blk, h, cur, l, last_out)
+                        continue
                 res = cur
                 if blk.downsample is not None:
                     res = add(blk.downsample[0], blk.downsample[1], cur, 0, l, l, relu=False)
-                cur = add(blk.conv2, blk.norm2, h, 1, l, l, relu=True, res=res, out=out if bi == len(blocks) - 1 else None)
+                cur = add(blk.conv2, blk.norm2, h, 1, l, l, relu=True, res=res, out=last_out)
             return cur
 
         slab = [new_buf(l, up_c[l] + skip_c[l]) for l in range(4)]
@@ -216,7 +271,7 @@ class MinkUNet(nn.Module):
         ops_arr = (N.UnetOp * len(ops))(*ops)
         bufs_arr = (N.UnetBuf * len(bufs))(*[N.UnetBuf(lv, w) for lv, w in bufs])
         return dict(ops=ops_arr, n_ops=len(ops), bufs=bufs_arr, n_bufs=len(bufs), out_buf=final[0], cin_p=cin_p,
-                    out_width=bufs[final[0]][1], keep=keep, true_io=true_io)
+                    out_width=bufs[final[0]][1], keep=keep, true_io=true_io, folded_io=folded_io)
 
     def _forget_state_tensors(self):
         self.__dict__.pop("_state_tensors", None)

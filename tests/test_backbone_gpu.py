@@ -190,8 +190,16 @@ def test_unet_matches_golden_and_oracle(arch, golden_dir):
     with torch.no_grad():
         type(m).MORTON = False
         fused_plain = m(x).F.cpu()
+        # the Python-issued plan launches the 1x1 shortcuts separately: bit-identity holds against the executor doing the same
+        from pbnet_amd.network import mink_unet as U_
+        U_.MinkUNet.FOLD_SHORTCUT = False
+        m._plans.clear()
+        fused_plain_sep = m(x).F.cpu()
+        U_.MinkUNet.FOLD_SHORTCUT = True
+        m._plans.clear()
         type(m).MORTON = True
-    assert torch.equal(fused_plain, fused_py), "native executor and Python-issued fused path must be bit-identical"
+    assert torch.equal(fused_plain_sep, fused_py), "native executor and Python-issued fused path must be bit-identical"
+    _close(fused_plain, fused_py, "shortcuts folded into the second convolutions vs separate launches", 1e-5)
     _close(fused, want_eval, arch + " fused eval path")
     _close(unfused, want_eval, arch + " module eval path")
     m.train()
@@ -430,3 +438,78 @@ def test_wave_family_configurations(dtype, tol, cin, cout, k):
                tol if dtype == torch.float32 else tol * max(1.0, want.abs().max().item()))
         ran += 1
     assert ran >= 3
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL), (torch.bfloat16, 6e-2), (torch.float16, 1e-2)])
+@pytest.mark.parametrize("cin,cin2,cout", [(64, 32, 64), (96, 128, 96), (128, 192, 128), (256, 384, 256)])
+def test_shortcut_folded_into_the_second_convolution(dtype, tol, cin, cin2, cout):
+    """pbn_spconv_forward_dual (round 4): relu(bn2(conv2(h)) + bn_d(conv1x1(x))) of a BasicBlock with a shortcut
+    (/root/reference/network/Mink.py:77-87,140-160) as ONE convolution over two sources, in every kernel family, against
+    the oracle's two convolutions."""
+    from pbnet_amd.MinkowskiEngine.conv import spconv_forward_dual, pack_weight, _pad_vec
+    from pbnet_amd.network.mink_unet import _group_steps
+    coords = _scene_coords(49, room=(1.0, 0.8, 0.6), batch=1)
+    n = len(coords)
+    torch.manual_seed(cin + cin2 + cout)
+    h, x = torch.randn(n, cin), torch.randn(n, cin2)
+    k2, kd = torch.randn(27, cin, cout) * (2.0 / (27 * cin)) ** 0.5, torch.randn(1, cin2, cout) * (1.0 / cin2) ** 0.5
+    s2, b2, sd, bd = torch.rand(cout) + 0.5, torch.randn(cout) * 0.1, torch.rand(cout) + 0.5, torch.randn(cout) * 0.1
+    q = (lambda t: t.to(dtype).float())
+    cm_ref = R.CoordinateManager(coords)
+    want = torch.relu(R.conv(q(h), q(k2 * s2), cm_ref.get_map(1, 1, 3), n) + b2 + q(x) @ q(kd[0] * sd) + bd)
+    st = ME.SparseTensor(torch.zeros(n, 1), torch.from_numpy(coords), device=DEV)
+    nbr = st.coordinate_manager.kernel_map(1, 3)
+    w2, vpo, n_main, cout_p = pack_weight((k2 * s2).to(DEV), dtype)
+    wd, vpo2, n2, _ = pack_weight((kd * sd).to(DEV), dtype)
+    pad = (-n2) % _group_steps(vpo // 4)
+    w = torch.cat([w2, wd] + ([torch.zeros(pad, *wd.shape[1:], dtype=wd.dtype, device=DEV)] if pad else []), 0).contiguous()
+    e = 16 // torch.empty(0, dtype=dtype).element_size()
+    hd = torch.zeros(n, vpo * e, dtype=dtype, device=DEV); hd[:, :cin] = h.to(dtype).to(DEV)
+    xd = torch.zeros(n, vpo2 * e, dtype=dtype, device=DEV); xd[:, :cin2] = x.to(dtype).to(DEV)
+    shift = _pad_vec((b2 + bd).to(DEV), cout_p, 0.0)
+    lim = tol if dtype == torch.float32 else tol * max(1.0, want.abs().max().item())
+    ran = 0
+    for cfg in (0, 16, 32, 64, 401, 402, 404, 406, 408, 204, 206, 208, 1401, 1402, 1404, 1201, 1202, 1204, 1208):
+        if cfg >= 100 and (cout_p // 16) % (cfg % 100):
+            continue
+        try:
+            o1 = spconv_forward_dual(hd, nbr, n, xd, (w, vpo, n_main + n2 + pad, cout_p), vpo2, shift=shift, relu=True, rows_per_wave=cfg)
+        except RuntimeError as ex:
+            assert "UNSUPPORTED" in str(ex), ex
+            continue
+        o2 = spconv_forward_dual(hd, nbr, n, xd, (w, vpo, n_main + n2 + pad, cout_p), vpo2, shift=shift, relu=True, rows_per_wave=cfg)
+        assert torch.equal(o1, o2), "cfg %d not deterministic" % cfg
+        _close(o1[:, :cout].float().cpu(), want, "dual cfg %d %d+%d->%d %s" % (cfg, cin, cin2, cout, dtype), lim)
+        ran += 1
+    assert ran >= 5
+
+
+@pytest.mark.parametrize("arch", ["MinkUNet14A", "MinkUNet34C"])
+def test_folded_shortcuts_equal_separate_launches(arch):
+    """The fused forward with the 1x1 shortcuts folded (default) against the same network with separate launches: fp32, 1e-4;
+    7 convolution launches fewer per network."""
+    from pbnet_amd.network import mink_unet as U
+    coords = _scene_coords(45, room=(0.9, 0.7, 0.5), batch=2)
+    torch.manual_seed(3)
+    feats = torch.randn(len(coords), 6)
+    net = Mink_unet(6, 20, arch=arch).to(DEV).eval()
+    g = torch.Generator().manual_seed(7)
+    for mod in net.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+            mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+    outs, nops = {}, {}
+    for fold in (True, False):
+        U.MinkUNet.FOLD_SHORTCUT = fold
+        try:
+            net._plans.clear()
+            with torch.no_grad():
+                outs[fold] = net(ME.SparseTensor(feats, torch.from_numpy(coords), device=DEV)).F.float().cpu()
+            nops[fold] = net._plan(torch.float32)["n_ops"]
+        finally:
+            U.MinkUNet.FOLD_SHORTCUT = True
+    net._plans.clear()
+    assert nops[False] - nops[True] == 7, nops
+    _close(outs[True], outs[False], "%s folded vs separate shortcuts" % arch)
