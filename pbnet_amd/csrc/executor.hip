@@ -7,7 +7,9 @@
 //                       folded into the convolution epilogues and skip concatenations written in place.
 // Both only sequence the kernels of coords.hip / spconv.hip; no new arithmetic lives here.
 #include <cstdlib>
+#include <cstring>
 #include "pbn_common.h"
+#include "spconv_common.h"
 
 using namespace pbn;
 
@@ -247,6 +249,22 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
         const void* in = base(o.in_buf) + (size_t)o.in_col * es;
         void* out = base(o.out_buf) + (size_t)o.out_col * es;
         const void* res = o.res_buf >= 0 ? base(o.res_buf) + (size_t)o.res_col * es : nullptr;
+        // the NEXT op's packed weights are touched by this op's workgroups (spconv_common.h: prefetch_next_weights)
+        g_next_weights = NextWeights{nullptr, 0, 0, 0, 0};
+        if (i + 1 < n_ops) {
+            const pbn_unet_op& q = ops[i + 1];
+            if (q.in_buf >= 0 && q.in_buf < n_bufs && q.level_in >= 0 && q.level_in <= 4 && q.level_out >= 0 && q.level_out <= 4 && q.w) {
+                ConvArgs nx;
+                memset(&nx, 0, sizeof(nx));
+                nx.K = q.map_kind == 0 ? 1 : (q.map_kind == 1 ? 27 : (q.map_kind == 2 ? 125 : 8));
+                nx.vpo = q.vpo; nx.n_steps = q.n_steps; nx.ntiles_total = q.cout_p / 16; nx.n_out = n_rows[q.level_out];
+                nx.w_bytes = (unsigned)((unsigned long long)q.n_steps * (q.cout_p / 16) * 1024ull);
+                nx.in_bytes = (unsigned)((unsigned long long)n_rows[q.level_in] * ld(q.in_buf) * es);
+                LaunchDesc d;
+                describe_launch(nx, dtype, &d);
+                g_next_weights = NextWeights{q.w, q.n_steps, q.cout_p / 16, d.wave_family ? d.nt : 0, d.wmajor ? d.groups : 0};
+            }
+        }
         if (events) PBN_HIP_CHECK(hipEventRecord(events[2 * i], (hipStream_t)stream));
         int rc;
         if (o.in2_buf >= 0) {           // a BasicBlock's 1x1 shortcut folded into this convolution's reduction
@@ -262,6 +280,7 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
                                     n_rows_dev ? n_rows_dev + o.level_out : nullptr, n_rows[o.level_out], o.w, o.vpo,
                                     o.n_steps, o.cout_p, o.scale, o.shift, res, o.res_buf >= 0 ? ld(o.res_buf) : 0,
                                     o.relu, out, ld(o.out_buf), dtype, 0, splitk_ws, splitk_bytes, stream);
+        g_next_weights = NextWeights{nullptr, 0, 0, 0, 0};
         if (rc != PBN_OK) return rc;
         if (events) PBN_HIP_CHECK(hipEventRecord(events[2 * i + 1], (hipStream_t)stream));
     }

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform for the compiler
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
+    if (blockIdx.y == 0 && blockIdx.z == 0) prefetch_next_weights(a, blockIdx.x, gridDim.x, tid, CONV_TPB);
     const int row0 = xcd_tile(blockIdx.x, gridDim.x) * TM;
 #ifdef PBN_CONV_TIMING
     __shared__ unsigned s_time[NW * 64 * 8];
@@ -602,6 +603,12 @@ static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const i
     a.relu = relu;
     a.ksplit = 1; a.partial = nullptr; a.n_out_pad = 0; a.cg = 1; a.wmajor = 0;
     a.in2 = in2_feat; a.ld_in2 = ld_in2; a.vpo2 = vecs_second; a.n_main = n_main; a.in2_bytes = (unsigned)in2_extent;
+    static const int pf_env = getenv("PBN_CONV_PREFETCH") ? atoi(getenv("PBN_CONV_PREFETCH")) : 1;   // 0 off, 1 with ownership, 2 plain slices
+    a.pf_w = nullptr; a.pf_steps = a.pf_ntt = a.pf_nt = a.pf_groups = 0;
+    if (pf_env && g_next_weights.w) {
+        a.pf_w = g_next_weights.w; a.pf_steps = g_next_weights.steps; a.pf_ntt = g_next_weights.ntt;
+        a.pf_nt = g_next_weights.nt; a.pf_groups = pf_env == 1 ? g_next_weights.groups : 0;
+    }
     static const int dbg_env = getenv("PBN_CONV_DBG") ? atoi(getenv("PBN_CONV_DBG")) : 0;
     a.dbg = dbg_env;
     // coarse levels (and whatever PBN_CONV_FAMILY selects): the wave-autonomous family of spconv_wave.hip -- K split over
@@ -622,6 +629,8 @@ static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const i
         default: return PBN_ERR_ARG;
     }
 }
+
+namespace pbn { thread_local NextWeights g_next_weights = {nullptr, 0, 0, 0, 0}; }
 
 extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
                                   const int32_t* row_perm, const int32_t* n_out_dev, int n_out, const void* w_packed,

@@ -38,7 +38,17 @@ struct ConvArgs {
     const void* in2;
     int ld_in2, vpo2, n_main;
     unsigned in2_bytes;
+    // next op's packed weights (round 4): every workgroup of THIS launch touches a slice of them so that they are in the L2
+    // of the XCD that will read them (weight-major launches: an XCD owns channel-tile groups) or at least in the memory-side
+    // cache when the next launch starts.  pf_groups = channel-tile groups of the next launch (0 = no ownership: plain slices)
+    const void* pf_w;
+    int pf_steps, pf_ntt, pf_nt, pf_groups;
 };
+
+// what the executor knows about the launch an op will turn into (spconv_wave.hip: describe_launch)
+struct LaunchDesc { int wave_family, nt, groups, wmajor; };
+struct NextWeights { const void* w; int steps, ntt, nt, groups; };
+extern thread_local NextWeights g_next_weights;     // set by the executor around pbn_spconv_forward (spconv.hip)
 
 namespace {
 
@@ -106,6 +116,40 @@ template <> __device__ __forceinline__ void store4<__half>(__half* p, const f32x
     *reinterpret_cast<uint2*>(p) = o;
 }
 
+// Touch this workgroup's share of the next op's weights (1 KiB pieces [step][channel tile][64 lanes][16 B]): loads into a
+// register nobody reads, never waited for (they retire while the main loop runs).  With ownership, the blocks of XCD x
+// (blockIdx % 8) share the pieces of the groups that XCD will read; without, all blocks share all pieces.
+__device__ __forceinline__ void prefetch_next_weights(const ConvArgs& a, int block, int n_blocks, int tid, int tpb) {
+    if (!a.pf_w) return;
+    const int lane = tid & 63, wave = tid >> 6, waves = tpb >> 6;
+    int owners = 1, xcd = 0, n_owned = a.pf_ntt / (a.pf_nt > 0 ? a.pf_nt : 1), g0 = 0, gstride = 1;
+    if (a.pf_groups > 0) {
+        xcd = block & 7;
+        owners = 8;
+        if (a.pf_groups >= 8) { g0 = xcd; gstride = 8; n_owned = (a.pf_groups - xcd + 7) >> 3; }
+        else { g0 = xcd % a.pf_groups; gstride = a.pf_groups; n_owned = 1; }
+    } else {
+        n_owned = 1;                                  // one "group" spanning all tiles
+    }
+    const int nt = a.pf_groups > 0 ? a.pf_nt : a.pf_ntt;
+    const int rank = a.pf_groups > 0 ? (block >> 3) : block;
+    const int nrank = a.pf_groups > 0 ? (n_blocks + 7 - xcd) >> 3 : n_blocks;
+    const long long pieces = (long long)a.pf_steps * n_owned * nt;
+    const long long per = (pieces + (nrank > 0 ? nrank : 1) - 1) / (nrank > 0 ? nrank : 1);
+    const long long lo = (long long)rank * per, hi = lo + per < pieces ? lo + per : pieces;
+    (void)owners;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(a.pf_w);
+    for (long long q = lo + wave; q < hi; q += waves) {
+        const int s = (int)(q / (n_owned * nt));
+        const int rem = (int)(q - (long long)s * (n_owned * nt));
+        const int gi = rem / nt, t = rem - gi * nt;
+        const int tile = (g0 + gi * gstride) * nt + t;
+        const u32x4* src = reinterpret_cast<const u32x4*>(base + ((size_t)s * a.pf_ntt + tile) * 1024) + lane;
+        u32x4 sink;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(src) : "memory");
+    }
+}
+
 __device__ __forceinline__ int xcd_tile(int b, int nt) {  // contiguous tile range per XCD (bijective for any nt)
     const int q = nt >> 3, r = nt & 7, xcd = b & 7, idx = b >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -117,6 +161,8 @@ __device__ __forceinline__ int xcd_tile(int b, int nt) {  // contiguous tile ran
 int launch_wave(const ConvArgs& a, int dtype, int force_cfg, hipStream_t stream);
 // spconv_wave.hip: which levels take the wave-autonomous family (rows of the output level, shapes)
 bool wave_family_wanted(const ConvArgs& a, int dtype);
+// spconv_wave.hip: channel tiles per workgroup / groups / block order of the launch `a` will become (automatic configuration)
+void describe_launch(const ConvArgs& a, int dtype, LaunchDesc* d);
 
 // spconv_halo.hip: LDS-staged family over halo tables (pbn_halo_build); PBN_ERR_UNSUPPORTED when the shape is not built
 bool halo_supported(const ConvArgs& a, int tile_rows);

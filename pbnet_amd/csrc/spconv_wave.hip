@@ -158,6 +158,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     PBN_WSTAMP(7);
     PBN_WSTAMP(0);
     const int n_groups = a.ntiles_total / NT;
+    prefetch_next_weights(a, blockIdx.x, gridDim.x, tid, TPB);
     const TileMap tm = map_block(a, (a.n_out + TM - 1) / TM, n_groups);
     if (!tm.valid) return;
     const int row0 = tm.row_tile * TM;
@@ -601,6 +602,21 @@ int launch_wave(const ConvArgs& a, int dtype, int force_cfg, hipStream_t stream)
 // quad-coalesced gathers): the K-split wave kernel is ahead of the workgroup-tile kernel + its split-K reduce launch on every
 // level below 20 k rows up to ~1e10 dense MACs (rows x K x C_in x C_out; L3 384->256 30.3 against 40.2 us, L2 128->128 28.8
 // against 33.8), and behind it on the wide levels (L1 96->96 48.5 against 38.0, L0 96->96 116 against 74.5).
+void describe_launch(const ConvArgs& a, int dtype, LaunchDesc* d) {
+    d->wave_family = 0; d->nt = 0; d->groups = 0; d->wmajor = 0;
+    if (!wave_family_wanted(a, dtype)) return;
+    static const int force_cfg = getenv("PBN_WAVE_CFG") ? atoi(getenv("PBN_WAVE_CFG")) : 0;
+    const int cfg = force_cfg > 0 ? force_cfg : pick_cfg(a);
+    const int nt = cfg % 100;
+    if (nt <= 0 || a.ntiles_total % nt) return;
+    d->wave_family = 1;
+    d->nt = nt;
+    d->groups = a.ntiles_total / nt;
+    const bool shape_ok = d->groups >= 8 ? (d->groups % 8 == 0) : (d->groups == 1 || d->groups == 2 || d->groups == 4);
+    static const int wmajor_env = getenv("PBN_WAVE_WMAJOR") ? atoi(getenv("PBN_WAVE_WMAJOR")) : 2;
+    d->wmajor = (cfg >= 1000 && (wmajor_env == 1 || (wmajor_env == 2 && a.w_bytes > a.in_bytes)) && shape_ok && d->groups > 1) ? 1 : 0;
+}
+
 bool wave_family_wanted(const ConvArgs& a, int dtype) {
     (void)dtype;
     static const int fam = getenv("PBN_CONV_FAMILY") ? atoi(getenv("PBN_CONV_FAMILY")) : 2;
