@@ -92,14 +92,15 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform for the compiler
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
-    if (blockIdx.y == 0 && blockIdx.z == 0) prefetch_next_weights(a, blockIdx.x, gridDim.x, tid, CONV_TPB);
+    u32x4 pf_sink = {0u, 0u, 0u, 0u};
+    if (blockIdx.y == 0 && blockIdx.z == 0) pf_sink = prefetch_next_weights(a, blockIdx.x, gridDim.x, tid, CONV_TPB);
     const int row0 = xcd_tile(blockIdx.x, gridDim.x) * TM;
 #ifdef PBN_CONV_TIMING
     __shared__ unsigned s_time[NW * 64 * 8];
     const bool timed_ = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0;
     if (timed_) for (int e = tid; e < NW * 64 * 8; e += CONV_TPB) s_time[e] = 0u;
 #endif
-    if (row0 >= n) return;
+    if (row0 >= n) { prefetch_drain(pf_sink); return; }
     const int tile0 = blockIdx.y * NT;
 
     for (int k = tid; k <= K; k += CONV_TPB) s_valid[k] = 0;
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
             s_nbr[r * KS + k] = v;
         }
     }
+    prefetch_drain(pf_sink);          // behind the rulebook loads: nothing new to wait for
     __syncthreads();
     // per offset: bitmask of the 16-row fragments that have at least one neighbour there
     for (int e = tid; e < K * NFRAG; e += CONV_TPB) {
@@ -603,7 +605,11 @@ static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const i
     a.relu = relu;
     a.ksplit = 1; a.partial = nullptr; a.n_out_pad = 0; a.cg = 1; a.wmajor = 0;
     a.in2 = in2_feat; a.ld_in2 = ld_in2; a.vpo2 = vecs_second; a.n_main = n_main; a.in2_bytes = (unsigned)in2_extent;
-    static const int pf_env = getenv("PBN_CONV_PREFETCH") ? atoi(getenv("PBN_CONV_PREFETCH")) : 1;   // 0 off, 1 with ownership, 2 plain slices
+    // Next-op weight prefetch, measured round 4 on the bench scene: one scene alone the stride-8 / 16
+    // ops gain 0.9 us each (138 convolution ops 3417 -> 3362 us with XCD ownership, 3354 with plain slices), with four scenes
+    // in flight the job LOSES 3-8 % (320 / 315 -> 299 / 289 scenes/s with ownership, 311 plain): the touched weights compete
+    // with the other scenes' working sets for the same L2s and every op reads 1.1 MB more.  Off by default.
+    static const int pf_env = getenv("PBN_CONV_PREFETCH") ? atoi(getenv("PBN_CONV_PREFETCH")) : 0;   // 0 off, 1 with ownership, 2 plain slices
     a.pf_w = nullptr; a.pf_steps = a.pf_ntt = a.pf_nt = a.pf_groups = 0;
     if (pf_env && g_next_weights.w) {
         a.pf_w = g_next_weights.w; a.pf_steps = g_next_weights.steps; a.pf_ntt = g_next_weights.ntt;

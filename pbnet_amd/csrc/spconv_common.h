@@ -119,8 +119,13 @@ template <> __device__ __forceinline__ void store4<__half>(__half* p, const f32x
 // Touch this workgroup's share of the next op's weights (1 KiB pieces [step][channel tile][64 lanes][16 B]): loads into a
 // register nobody reads, never waited for (they retire while the main loop runs).  With ownership, the blocks of XCD x
 // (blockIdx % 8) share the pieces of the groups that XCD will read; without, all blocks share all pieces.
-__device__ __forceinline__ void prefetch_next_weights(const ConvArgs& a, int block, int n_blocks, int tid, int tpb) {
-    if (!a.pf_w) return;
+// The destination register is returned and must stay allocated until the loads have landed: the caller names it in
+// prefetch_drain() behind its own first loads (the rulebook tile), whose wait covers these older loads anyway -- a load that
+// lands in a register the compiler has meanwhile given to an address is a memory fault (seen).
+__device__ __forceinline__ void prefetch_drain(u32x4& sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)); }
+__device__ __forceinline__ u32x4 prefetch_next_weights(const ConvArgs& a, int block, int n_blocks, int tid, int tpb) {
+    u32x4 sink = {0u, 0u, 0u, 0u};
+    if (!a.pf_w) return sink;
     const int lane = tid & 63, wave = tid >> 6, waves = tpb >> 6;
     int owners = 1, xcd = 0, n_owned = a.pf_ntt / (a.pf_nt > 0 ? a.pf_nt : 1), g0 = 0, gstride = 1;
     if (a.pf_groups > 0) {
@@ -145,9 +150,9 @@ __device__ __forceinline__ void prefetch_next_weights(const ConvArgs& a, int blo
         const int gi = rem / nt, t = rem - gi * nt;
         const int tile = (g0 + gi * gstride) * nt + t;
         const u32x4* src = reinterpret_cast<const u32x4*>(base + ((size_t)s * a.pf_ntt + tile) * 1024) + lane;
-        u32x4 sink;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(src) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(src) : "memory");     // same register: loads land in order
     }
+    return sink;
 }
 
 __device__ __forceinline__ int xcd_tile(int b, int nt) {  // contiguous tile range per XCD (bijective for any nt)

@@ -158,9 +158,9 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     PBN_WSTAMP(7);
     PBN_WSTAMP(0);
     const int n_groups = a.ntiles_total / NT;
-    prefetch_next_weights(a, blockIdx.x, gridDim.x, tid, TPB);
+    u32x4 pf_sink = prefetch_next_weights(a, blockIdx.x, gridDim.x, tid, TPB);
     const TileMap tm = map_block(a, (a.n_out + TM - 1) / TM, n_groups);
-    if (!tm.valid) return;
+    if (!tm.valid) { prefetch_drain(pf_sink); return; }
     const int row0 = tm.row_tile * TM;
     const int tile0 = tm.group * NT;
     const int g = lane >> 4, rl = lane & 15;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
         }
     }
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
-    if (row0 >= n) return;
+    if (row0 >= n) { prefetch_drain(pf_sink); return; }
     if (tid == 0) *s_none = -1;
 
     // ---- rulebook tile -> LDS ----
@@ -241,6 +241,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
             s_nbr[r * KS + k] = v;
         }
     }
+    prefetch_drain(pf_sink);          // behind the rulebook loads: nothing new to wait for
     __syncthreads();
     PBN_WSTAMP(1);
 
