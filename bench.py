@@ -84,7 +84,7 @@ def pin_rank_to_cpus(local_rank, ranks_on_node):
     try:
         cores = sorted(os.sched_getaffinity(0))
         per = len(cores) // ranks_on_node
-        if per < 1:
+        if per < 2:                         # a rank's four scene threads on one core would be worse than no pinning
             return None
         mine = cores[local_rank * per:(local_rank + 1) * per]
         os.sched_setaffinity(0, mine)
