@@ -15,6 +15,7 @@ static plan (the train-mode twin of MinkUNet._build_plan):
 
 Same kernels, same order and the same arithmetic as the module path (tests/test_train_engine_gpu.py compares the two)."""
 import ctypes
+import weakref
 import os
 
 import torch
@@ -274,7 +275,8 @@ def _pair_array(pyr, plan):
 
 class _State(object):
     """What the backward needs from the forward (attributes of the autograd context)."""
-    __slots__ = ("plan", "pyr", "padded", "arena", "stats", "offs", "nbytes", "n_rows", "tables", "perm", "inv_perm")
+    __slots__ = ("plan", "pyr", "padded", "arena", "stats", "offs", "nbytes", "n_rows", "tables", "perm", "inv_perm",
+                 "param_versions", "out_ref", "out_version")
 
 
 class _BodyFn(torch.autograd.Function):
@@ -319,18 +321,33 @@ class _BodyFn(torch.autograd.Function):
         st.plan, st.pyr, st.padded, st.arena, st.stats, st.offs, st.nbytes, st.n_rows, st.tables = \
             plan, pyr, padded, arena, stats, offs, nbytes, n_rows, tables
         st.perm, st.inv_perm = perm, inv_perm
+        # the backward re-reads the activation arena (ReLU masks, batch-norm inputs) and the kernels behind the packed weights:
+        # autograd cannot see either (the arena is not a saved tensor), so their versions are checked by hand in backward()
+        st.param_versions = [int(p._version) for p in plan.params]
         ctx.state = st
         ctx.in_shape, ctx.in_dtype = (n, int(feats.shape[1])), feats.dtype
         ob, oc = plan.out_view
         width = plan.bufs[ob][1]
         out = arena[offs[ob]:offs[ob] + rows[0] * width * es].view(dt).view(rows[0], width)
         out = out[:, oc:oc + plan.out_channels] if (oc or width != plan.out_channels) else out
-        return out if inv_perm is None else out.index_select(0, inv_perm)      # external row i = stored row inv_perm[i]
+        out = out if inv_perm is None else out.index_select(0, inv_perm)       # external row i = stored row inv_perm[i]
+        st.out_ref, st.out_version = weakref.ref(out), int(out._version)       # an in-place op on the output would corrupt the arena
+        return out
 
     @staticmethod
     def backward(ctx, dout):
         st = ctx.state
+        if st is None:
+            raise RuntimeError("native training executor: backward ran twice through the same forward (retain_graph=True is not "
+                               "supported: the activation arena is released after the first backward; PBN_TRAIN_ENGINE=0 runs the modules)")
+        o_ = st.out_ref()
+        if o_ is not None and int(o_._version) != st.out_version:
+            raise RuntimeError("native training executor: the body's output was modified in place between forward and backward "
+                               "(it aliases the activation arena the backward reads)")
         plan, pyr = st.plan, st.pyr
+        if [int(p._version) for p in plan.params] != st.param_versions:
+            raise RuntimeError("native training executor: a parameter changed between forward and backward (an optimizer step or an "
+                               "in-place update): the packed weights of the forward no longer match")
         dt, dev = plan.dtype, dout.device
         lib = N.lib()
         es = torch.empty(0, dtype=dt).element_size()

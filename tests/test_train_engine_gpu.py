@@ -167,3 +167,31 @@ def test_engine_on_tiny_scenes(n_points):
     for k in ref[2]:
         assert torch.equal(got[2][k], ref[2][k]), k
         assert torch.isfinite(got[2][k]).all(), k
+
+
+def test_engine_refuses_what_autograd_cannot_see():
+    """The backward re-reads the activation arena and the packed kernels of the forward: a second backward through the same
+    forward, a parameter changed in between and (for the node's own output) an in-place modification are refused loudly."""
+    coords = _coords()
+    torch.manual_seed(7)
+    net = Mink_unet(6, 32, arch="MinkUNet14A").to(DEV).train()
+    feats = torch.randn(len(coords), 6, device=DEV)
+    TE.ENABLED, TE.SORTED = True, False
+
+    def fwd():
+        return net(ME.SparseTensor(feats, torch.from_numpy(coords).to(DEV))).F
+    out = fwd()
+    assert net.__dict__.get("_train_plans"), "the executor did not run"
+    out.float().sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="backward ran twice"):
+        out.float().sum().backward()
+    out = fwd()
+    with torch.no_grad():
+        net.conv0p1s1.kernel.add_(1e-3)            # what an optimizer step between forward and backward would do
+    with pytest.raises(RuntimeError, match="parameter changed"):
+        out.float().sum().backward()
+    for p in net.parameters():
+        p.grad = None
+    out = fwd()
+    out.float().sum().backward()                   # and the ordinary order still works
+    assert net.conv0p1s1.kernel.grad is not None
