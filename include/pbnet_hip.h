@@ -223,7 +223,7 @@ int pbn_halo_build(const pbn_halo_job* jobs, int n_jobs, pbn_stream_t stream);
  * lds_slots: rows of the LDS buffer (0 = default); a tile with more distinct rows runs once per segment of its list.
  * cfg: 0 = automatic; > 0: 10000 * depth + (1000 * ksplit + 100 * NF + NT), the configuration code of the wave-autonomous
  * family (pbn_spconv_forward, rows_per_wave >= 100) whose tile must match tile_rows, depth = weight stages in flight (0, 2,
- * 3); < 0: the barrier-synchronised experiment of csrc/spconv_halo.hip, -(100 * S + 10 * RING + CSP) -- explicit values
+ * 3); < 0: the barrier-synchronised experiment of csrc/spconv_halo.hip, -(100 * S + 10 * RING + CSP) with S 3..4, RING 2 -- explicit values
  * for tests and tuning.
  * PBN_ERR_UNSUPPORTED for shapes this family does not build (the caller falls back to pbn_spconv_forward). */
 int pbn_spconv_forward_halo(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
