@@ -170,6 +170,113 @@ __global__ __launch_bounds__(TPB) void k_mlp_rows(const T* __restrict__ in, int 
     }
 }
 
+// The same heads on the matrix cores (round 4).  k_mlp_rows is latency-bound per wave: every thread streams the 1 024 + H n_out
+// weights through scalar loads for 1 700 dependent FMAs (38 us for 161 k rows of a 32 -> 32 -> 32 head whose arithmetic is 3 us
+// of the vector ALUs).  Here a wave takes 16 rows per round on v_mfma_f32_16x16x4_f32 (exact fp32: an fmaf chain), both layers
+// TRANSPOSED so that no operand ever changes lanes:
+//   layer 1:  D1[h][row] = sum_c W1[h][c] x[row][c]      A = W1 (lane (kq, h) holds w1[h][8 kq + kb] for step kb),
+//                                                        B = x^T (lane (kq, row) holds the 8 channels 8 kq .. 8 kq + 7 of its row:
+//                                                        ONE 16-byte load for 16-bit slabs); D1: lane (q, row) = hidden 4 q + i
+//   layer 2:  D2[o][row] = sum_h W2[o][h] hid[row][h]    B = the D1 registers as they are (step (t, i): hidden 16 t + 4 kq + i),
+//                                                        A = W2 indexed accordingly; D2: lane (q, row) = outputs 4 q + i of its row
+// Weights, BatchNorm constants and slopes live in registers for the wave's whole loop over row blocks.  Summation order differs from
+// k_mlp_rows (channels 0, 8, 16, 24, 1, 9, ...): fp32 results agree to rounding (tests: 1e-5).
+typedef float mlp_f32x4 __attribute__((ext_vector_type(4)));
+template <typename T, int H, int U>
+__global__ __launch_bounds__(TPB) void k_mlp_rows_mfma(const T* __restrict__ in, int ld_in, const long long* __restrict__ idx_a,
+                                                      const long long* __restrict__ idx_b, int n_cap,
+                                                      const int* __restrict__ n_dev, long long in_rows,
+                                                      const float* __restrict__ w1, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, const float* __restrict__ slope,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2, int n_out,
+                                                      int sigmoid, T* __restrict__ out, int ld_out) {
+    constexpr int C = 32, HT = H / 16;
+    const int n = n_dev ? min(*n_dev, n_cap) : n_cap;
+    const int lane = threadIdx.x & 63, kq = lane >> 4, r = lane & 15;
+    const int wave = (int)((blockIdx.x * TPB + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * TPB) >> 6);
+    // ---- per-wave constants ----
+    float a1[HT][8];                 // layer-1 A operands: w1[16 t + r][8 kq + kb]
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) a1[t][kb] = w1[(16 * t + r) * C + 8 * kq + kb];
+    float sc[HT][4], sh[HT][4], sl[HT][4];      // of hidden 16 t + 4 kq + i (this lane's D1 registers)
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hh = 16 * t + 4 * kq + i;
+            sc[t][i] = scale[hh]; sh[t][i] = shift[hh]; sl[t][i] = slope[hh];
+        }
+    float a2[U][HT][4];              // layer-2 A operands: w2[16 u + r][16 t + 4 kq + i]
+    float bias[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int o = 16 * u + r;
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a2[u][t][i] = o < n_out ? w2[o * H + 16 * t + 4 * kq + i] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oo = 16 * u + 4 * kq + i;
+            bias[u][i] = (b2 && oo < n_out) ? b2[oo] : 0.0f;
+        }
+    }
+    for (int blk = wave; blk * 16 < n; blk += n_waves) {
+        const int i_row = blk * 16 + r;
+        long long row = -1;
+        if (i_row < n) {
+            row = idx_a ? idx_a[i_row] : i_row;
+            if (idx_b && row >= 0) row = idx_b[row];
+        }
+        const bool inside = row >= 0 && (in_rows < 0 || row < in_rows);
+        float x[8];
+        {
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(in + (size_t)(inside ? row : 0) * ld_in) + (size_t)kq * 8 * sizeof(T);
+            if constexpr (sizeof(T) == 4) {
+                const uint4 v0 = inside ? reinterpret_cast<const uint4*>(src)[0] : make_uint4(0u, 0u, 0u, 0u);
+                const uint4 v1 = inside ? reinterpret_cast<const uint4*>(src)[1] : make_uint4(0u, 0u, 0u, 0u);
+                RowIO<T>::unpack(v0, x);
+                RowIO<T>::unpack(v1, x + 4);
+            } else {
+                RowIO<T>::unpack(inside ? reinterpret_cast<const uint4*>(src)[0] : make_uint4(0u, 0u, 0u, 0u), x);
+            }
+        }
+        mlp_f32x4 d1[HT];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            d1[t] = mlp_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) d1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t][kb], x[kb], d1[t], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = fmaf(d1[t][i], sc[t][i], sh[t][i]);
+                d1[t][i] = v >= 0.f ? v : v * sl[t][i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            mlp_f32x4 d2 = mlp_f32x4{bias[u][0], bias[u][1], bias[u][2], bias[u][3]};
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[u][t][i], d1[t][i], d2, 0, 0, 0);
+            if (i_row < n) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int oo = 16 * u + 4 * kq + i;
+                    if (oo < n_out) {
+                        float v = d2[i];
+                        if (sigmoid) v = 1.0f / (1.0f + expf(-v));
+                        RowIO<T>::store(out + (size_t)i_row * ld_out + oo, v);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- semantic argmax + own-class softmax score + [class, batch] population table (PBNet.py:134,151-163) -------------
 // Block = SEL_BLOCK consecutive points.  Besides the global table it leaves the per-block class histogram that
 // k_select_points turns into stable output positions.
@@ -555,6 +662,34 @@ static int mlp_rows_impl(const void* in, int ld_in, long long in_rows, int chann
     if (!in || !w1 || !scale || !shift || !slope || !w2 || !out) return PBN_ERR_ARG;
     const int esz = dtype == PBN_F32 ? 4 : 2;
     if ((ld_in * esz) % 16 || ((uintptr_t)in & 15)) return PBN_ERR_ARG;
+    // matrix-core form (default; PBN_MLP_FORM=0: the scalar kernel, kept as the cross-check): 16 rows per wave and round
+    static const int form_env = getenv("PBN_MLP_FORM") ? atoi(getenv("PBN_MLP_FORM")) : 1;
+    if (form_env != 0 && n_out <= 32) {
+        const long long blocks16 = cdiv(n, 16);
+        // ~4 row blocks per wave: the ~60 register-resident weight words of a wave pay off (scripts/probe_heads.py, HIP-graph replay,
+        // 161 517 gathered rows, bf16: 32->32->32 35.3 -> 24.4 us, 32->16->20 16.8 -> 12.7, the 3- and 1-output heads 8.6 either way;
+        // one block per wave: no gain at all).  PBN_MLP_BLOCKS: row blocks per wave (measurement)
+        static const int bpw_env = getenv("PBN_MLP_BLOCKS") ? atoi(getenv("PBN_MLP_BLOCKS")) : 4;
+        long long wgs = cdiv(blocks16, (TPB / 64) * (bpw_env > 0 ? bpw_env : 1));
+        if (wgs > 8192) wgs = 8192;
+        if (wgs < 1) wgs = 1;
+        const dim3 g((unsigned)wgs);
+#define PBN_MLPM(TT, HH, UU)                                                                                            \
+        hipLaunchKernelGGL((k_mlp_rows_mfma<TT, HH, UU>), g, dim3(TPB), 0, stream, (const TT*)in, ld_in,                 \
+                           (const long long*)idx_a, (const long long*)idx_b, n, n_dev, in_rows, w1, scale, shift, slope, w2, b2, \
+                           n_out, sigmoid, (TT*)out, ld_out)
+#define PBN_MLPM_T(TT)                                                                                                  \
+        { if (hidden == 16) { if (n_out <= 16) PBN_MLPM(TT, 16, 1); else PBN_MLPM(TT, 16, 2); }                          \
+          else { if (n_out <= 16) PBN_MLPM(TT, 32, 1); else PBN_MLPM(TT, 32, 2); } }
+        if (dtype == PBN_F32) PBN_MLPM_T(float)
+        else if (dtype == PBN_BF16) PBN_MLPM_T(__hip_bfloat16)
+        else if (dtype == PBN_F16) PBN_MLPM_T(__half)
+        else return PBN_ERR_ARG;
+#undef PBN_MLPM_T
+#undef PBN_MLPM
+        PBN_LAUNCH_CHECK();
+        return PBN_OK;
+    }
     const dim3 grid(cdiv(n, TPB));
 #define PBN_MLP(TT, HH)                                                                                                 \
     hipLaunchKernelGGL((k_mlp_rows<TT, 32, HH>), grid, dim3(TPB), 0, stream, (const TT*)in, ld_in,                        \
