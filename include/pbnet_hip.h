@@ -581,7 +581,16 @@ typedef struct {
     int32_t level, width;
 } pbn_unet_buf;
 
+/* Optional halo tables of the lineage's k = 3 maps (pbn_halo_build), one per level or NULL: where a table is given and the op's
+ * shape is one the staged-row kernels win on (csrc/executor.hip: halo_wanted), the op runs on csrc/spconv_wave_halo.hip. */
+typedef struct {
+    const void* table[5];
+    pbn_halo_layout layout[5];
+} pbn_unet_halo;
+
 size_t pbn_unet_arena_bytes(const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows, int dtype, int64_t* buf_offsets);
+/* thread-local: the tables the NEXT pbn_unet_forward* call of this thread uses (NULL = none); cleared by that call */
+void pbn_unet_set_halo(const pbn_unet_halo* halo);
 int pbn_unet_forward_dev(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows_cap,
                          const int32_t* n_rows_dev, const void* input, int ld_input, const int32_t* const* k3,
                          const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,

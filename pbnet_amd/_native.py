@@ -51,6 +51,11 @@ class HaloJob(ctypes.Structure):
                 ("n_out", c_i32), ("max_rows", c_i32)]
 
 
+class UnetHalo(ctypes.Structure):
+    """pbn_unet_halo (include/pbnet_hip.h)."""
+    _fields_ = [("table", ctypes.c_void_p * 5), ("layout", HaloLayout * 5)]
+
+
 class UnetOp(ctypes.Structure):
     """pbn_unet_op (include/pbnet_hip.h)."""
     _fields_ = [("map_kind", c_i32), ("level_in", c_i32), ("level_out", c_i32),
@@ -166,6 +171,7 @@ SIGNATURES = {
     "pbn_coords_prepare": (c_int, [c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(PrepareLayout), c_vp]),
     "pbn_coords_prepare_dev": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(PrepareLayout), c_vp]),
     "pbn_coords_prepare_hash": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(PrepareLayout), c_vp]),
+    "pbn_unet_set_halo": (None, [ctypes.POINTER(UnetHalo)]),
     "pbn_unet_forward_dev": (c_int, [ctypes.POINTER(UnetOp), c_int, ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32),
                                      c_i32p, c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp,
                                      ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_vp, c_size, c_int,

@@ -218,11 +218,32 @@ extern "C" size_t pbn_unet_arena_bytes(const pbn_unet_buf* bufs, int n_bufs, con
     return off;
 }
 
+static thread_local const pbn_unet_halo* g_unet_halo = nullptr;
+extern "C" void pbn_unet_set_halo(const pbn_unet_halo* halo) { g_unet_halo = halo; }
+
+// Where the staged-row kernels pay (round 4, scripts/probe_halo.py with four streams on the bench scene's levels): K-split over
+// 64-row tiles on levels of 4 k - 20 k rows for every wide k = 3 layer up to 256 input channels (x1.2-1.5 in flight), on levels
+// of 2 k - 4 k rows for 128 / 256 input channels (x1.1-1.2; 384 -> 256 and the stride-16 level lose); a wave per 32 rows
+// (128-row tiles) on levels of 20 k - 70 k rows for 32-channel layers (x1.5).  PBN_UNET_HALO=0 switches it off.
+static bool halo_wanted(const pbn_unet_op& o, int rows, int tile_rows) {
+    static const int env = getenv("PBN_UNET_HALO") ? atoi(getenv("PBN_UNET_HALO")) : 1;
+    if (!env || o.map_kind != 1 || o.in2_buf >= 0 || (o.vpo & 3)) return false;
+    if (tile_rows == 64) {
+        if (rows >= 4000 && rows <= 20000) return o.vpo <= 32;
+        if (rows >= 2000 && rows < 4000) return o.vpo == 16 || o.vpo == 32;
+        return false;
+    }
+    if (tile_rows == 128) return rows >= 20000 && rows <= 70000 && o.vpo == 4;
+    return false;
+}
+
 static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs,
                              const int32_t* n_rows, const void* input, int ld_input, const int32_t* const* k3,
                              const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
                              size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream,
                              hipEvent_t* events, const int32_t* n_rows_dev = nullptr) {
+    const pbn_unet_halo* halo = g_unet_halo;
+    g_unet_halo = nullptr;
     if (!ops || !bufs || !n_rows || !input || !arena || n_ops < 1 || n_bufs < 2 || n_bufs > 512) return PBN_ERR_ARG;
     int64_t offs[512];
     if (pbn_unet_arena_bytes(bufs, n_bufs, n_rows, dtype, offs) > arena_bytes) return PBN_ERR_WORKSPACE;
@@ -266,8 +287,17 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
             }
         }
         if (events) PBN_HIP_CHECK(hipEventRecord(events[2 * i], (hipStream_t)stream));
-        int rc;
-        if (o.in2_buf >= 0) {           // a BasicBlock's 1x1 shortcut folded into this convolution's reduction
+        int rc = PBN_ERR_UNSUPPORTED;
+        if (halo && o.map_kind == 1 && halo->table[o.level_out] &&
+            halo_wanted(o, n_rows[o.level_out], halo->layout[o.level_out].tile_rows)) {
+            rc = pbn_spconv_forward_halo(in, ld(o.in_buf), n_rows[o.level_in], nbr, K, n_rows_dev ? n_rows_dev + o.level_out : nullptr,
+                                         n_rows[o.level_out], o.w, o.vpo, o.n_steps, o.cout_p, o.scale, o.shift, res,
+                                         o.res_buf >= 0 ? ld(o.res_buf) : 0, o.relu, out, ld(o.out_buf), dtype,
+                                         halo->table[o.level_out], &halo->layout[o.level_out], 0, 0, stream);
+        }
+        if (rc != PBN_ERR_UNSUPPORTED) {
+            // ran on the staged-row kernels (or failed there for another reason: reported below)
+        } else if (o.in2_buf >= 0) {           // a BasicBlock's 1x1 shortcut folded into this convolution's reduction
             if (o.in2_buf >= n_bufs) return PBN_ERR_ARG;
             const void* in2 = base(o.in2_buf) + (size_t)o.in2_col * es;
             rc = pbn_spconv_forward_dual(in, ld(o.in_buf), n_rows[o.level_in], nbr, K,
