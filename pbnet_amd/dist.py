@@ -84,7 +84,7 @@ class GradientReducer(object):
                 offs.append(off)
                 off += p.numel()
                 self._bucket_of[id(p)] = (bi, len(offs) - 1)
-            packed.append(dict(params=plist, offsets=offs, numel=off, flat=None, pending=len(plist), work=None,
+            packed.append(dict(params=plist, offsets=offs, numel=off, flat=None, views=None, pending=len(plist), work=None,
                                filled=[False] * len(plist)))
         self.buckets = packed
         self._index = {id(p): i for i, p in enumerate(self.params)}
@@ -126,48 +126,63 @@ class GradientReducer(object):
     # ---- per-gradient path (called by autograd during backward) ----------------------------------------------------
     def _flat(self, b, like):
         if b["flat"] is None or b["flat"].device != like.device:
-            b["flat"] = torch.zeros(b["numel"], dtype=self.comm_dtype, device=like.device)
+            b["flat"] = torch.empty(b["numel"], dtype=self.comm_dtype, device=like.device)
+            b["views"] = [b["flat"][o:o + p.numel()].view_as(p) for o, p in zip(b["offsets"], b["params"])]
+            b["typed"] = {}
         return b["flat"]
+
+    def _pack(self, b, like):
+        """Gradients of one bucket -> its flat buffer: ONE multi-tensor copy for the parameters that have a gradient on this
+        rank, one multi-tensor zero for those that do not (round 3 issued a copy per parameter from the hook: ~470 tiny
+        launches per step and as many again on the way back).  A gradient that already lives in the bucket (the views
+        finish() hands out, kept by zero_grad(set_to_none=False) or by gradient accumulation) is not copied onto itself."""
+        self._flat(b, like)
+        dst, src, zero = [], [], []
+        for v, p in zip(b["views"], b["params"]):
+            g = p.grad
+            if g is None:
+                zero.append(v)
+            elif g.data_ptr() != v.data_ptr() or g.dtype != v.dtype or not g.is_contiguous():
+                dst.append(v)
+                src.append(g.detach())
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if zero:
+            torch._foreach_zero_(zero)
 
     def _on_grad(self, p):
         bi, pi = self._bucket_of[id(p)]
         b = self.buckets[bi]
         if b["filled"][pi]:
-            # a second backward before finish(): the bucket holds (and may already have sent) the FIRST gradient only, the
+            # a second backward before finish(): the bucket may already have sent the FIRST gradient only, the
             # accumulated one would be lost -- refuse instead of averaging the wrong thing
             raise RuntimeError("GradientReducer: backward ran twice before finish(); with gradient accumulation build the "
                                "reducer with overlap=False (the all-reduce then starts in finish())")
-        flat = self._flat(b, p)
-        flat[b["offsets"][pi]:b["offsets"][pi] + p.numel()].copy_(p.grad.detach().reshape(-1))
         b["filled"][pi] = True
         b["pending"] -= 1
         # every rank must issue the same collectives in the same order: buckets go out strictly by index (a bucket
         # that completes early waits for its predecessors; what backward never completes is issued by finish())
         while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
             nb = self.buckets[self._next]
+            self._pack(nb, p)
             nb["work"] = dist.all_reduce(nb["flat"], op=dist.ReduceOp.SUM, async_op=True)
             self._next += 1
 
     # ---- after backward -------------------------------------------------------------------------------------------
     def finish(self):
-        """Issue what backward did not, wait, write the averaged gradients back.  Returns the number of buckets."""
+        """Issue what backward did not, wait, hand the averaged gradients back.  Returns the number of buckets.
+        After finish() `p.grad` is a VIEW of its bucket (fp32 on the wire; a converted copy of the bucket otherwise): no
+        copy back, the optimiser reads the bucket.  The bucket is rewritten by the next step's backward."""
         if self.world == 1:
             return 0
         dev = next((p.grad.device for p in self.params if p.grad is not None), self.params[0].device)
         on_host = self._host_group is not None or dist.get_backend() == "gloo"
         used = torch.tensor([1 if p.grad is not None else 0 for p in self.params], dtype=torch.int32,
                             device="cpu" if on_host else dev)
+        like = torch.empty(0, device=dev)
         for b in self.buckets[self._next:]:
-            flat = self._flat(b, self.params[0] if dev is None else torch.empty(0, device=dev))
-            for pi, p in enumerate(b["params"]):
-                if b["filled"][pi]:
-                    continue
-                sl = flat[b["offsets"][pi]:b["offsets"][pi] + p.numel()]
-                if p.grad is not None:           # gradients produced without the hook path (overlap=False)
-                    sl.copy_(p.grad.detach().reshape(-1))
-                else:
-                    sl.zero_()
-            b["work"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            self._pack(b, like)
+            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
         used_work = dist.all_reduce(used, op=dist.ReduceOp.MAX, async_op=True, group=self._host_group)
         self._next = 0
         used_work.wait()
@@ -175,15 +190,19 @@ class GradientReducer(object):
         for b in self.buckets:
             b["work"].wait()
             flat = b["flat"]
+            flat.div_(self.world)                # one launch per bucket
+            typed = {}
             for pi, p in enumerate(b["params"]):
                 if not used_h[self._index[id(p)]]:
                     p.grad = None                # unused on every rank: the optimiser must skip it (DDP semantics)
                     continue
-                g = flat[b["offsets"][pi]:b["offsets"][pi] + p.numel()].view_as(p)
-                if p.grad is None:
-                    p.grad = (g / self.world).to(p.dtype)
+                if p.dtype == flat.dtype:
+                    p.grad = b["views"][pi]
                 else:
-                    p.grad.copy_(g / self.world)
+                    if p.dtype not in typed:
+                        typed[p.dtype] = flat.to(p.dtype)         # one conversion per bucket and dtype
+                    o = b["offsets"][pi]
+                    p.grad = typed[p.dtype][o:o + p.numel()].view_as(p)
             b["work"], b["pending"], b["filled"] = None, len(b["params"]), [False] * len(b["params"])
         return len(self.buckets)
 

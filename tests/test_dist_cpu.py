@@ -69,6 +69,22 @@ def _worker(rank, world, port, out):
     pd.allreduce_gradients(net3.parameters(), bucket_bytes=256, comm_dtype=torch.bfloat16)
     for pa, pb in zip(net.parameters(), net3.parameters()):
         ok = ok and (pa.grad is None or torch.allclose(pa.grad, pb.grad, rtol=2e-2, atol=1e-2))
+    # (3b) gradients that already live in the bucket: finish() hands out views of the flat buffer; zero_grad(set_to_none=False)
+    # keeps them, two backwards accumulate into them in place (overlap=False), the second round packs nothing onto itself
+    net4 = make()
+    red4 = pd.GradientReducer(net4.parameters(), bucket_bytes=256, overlap=False)
+    for rnd in range(2):
+        for p in net4.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        for _ in range(2):
+            h = net4[0](x)
+            (net4[1](h).sum() if rank == 0 else h.sum()).backward()
+        red4.finish()
+        for pa, pb in zip(net.parameters(), net4.parameters()):
+            ok = ok and ((pa.grad is None) == (pb.grad is None)) and (pa.grad is None or torch.allclose(2 * pa.grad, pb.grad, atol=1e-6))
+        views = [b["views"][i].data_ptr() for b in red4.buckets for i in range(len(b["params"]))]
+        ok = ok and all(p.grad is None or p.grad.data_ptr() in views for p in net4.parameters())
     # (4) BatchNorm statistics: every rank ends with rank 0's buffers
     with torch.no_grad():
         net[3].running_mean.fill_(float(rank + 1))
