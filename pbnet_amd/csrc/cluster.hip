@@ -663,18 +663,23 @@ __device__ __forceinline__ float exact_quotient(float d, float n, float y) {
 }
 
 constexpr int CTR_TPB = 64;
+constexpr int CTR_SUB = 4;                       // 64-point slices per chunk
+constexpr int CTR_CHUNK = CTR_TPB * CTR_SUB;     // segment points compacted per round
 __global__ __launch_bounds__(CTR_TPB) void k_centers(const int* __restrict__ cluster_id, const float* __restrict__ off_xyz,
                                                     const int* __restrict__ clt_seg, const int* __restrict__ seg_off,
                                                     const int* __restrict__ n_clusters_total,
                                                     const int* __restrict__ member_start, int* __restrict__ member_idx,
                                                     float* __restrict__ centers) {
-    // a16 + members CSR: one 64-lane workgroup per final cluster walks its segment in index order.  Each 64-point
+    // a16 + members CSR: one 64-lane workgroup per final cluster walks its segment in index order.  Each 256-point
     // chunk is compacted (ballot prefix) into LDS; lanes 0..2 then advance the sequential running mean
     // M += (p - M)/N (binary_cuda_functions.cu:237-239) of x, y, z.  A single wave is issue-bound, so the chain is kept
-    // to five instructions per member: the 64 reciprocals 1/N of a chunk are computed by all lanes at once and the
-    // quotient is a multiply + two FMAs (exact, see exact_quotient).  The next chunk's loads are issued before the chain.
-    __shared__ float s_xyz[3][CTR_TPB];
-    __shared__ float s_rcp[CTR_TPB];
+    // to five instructions per member: the reciprocals 1/N of a chunk are computed by all lanes at once and the
+    // quotient is a multiply + two FMAs (exact, see exact_quotient).  Round 4: the members reach the chain in registers,
+    // sixteen at a time and one group AHEAD of the chain (the LDS round trip of a group used to sit in front of every four
+    // members), and a chunk is 256 segment points (the compaction, its two barriers and the reciprocals once per ~120
+    // members instead of once per ~30).  The next chunk's global loads are issued before the chain.
+    __shared__ __attribute__((aligned(16))) float s_xyz[3][CTR_CHUNK + 32];
+    __shared__ __attribute__((aligned(16))) float s_rcp[CTR_CHUNK + 32];
     const int lane = threadIdx.x;
     const int C = *n_clusters_total;
     for (int c = blockIdx.x; c < C; c += gridDim.x) {
@@ -683,52 +688,86 @@ __global__ __launch_bounds__(CTR_TPB) void k_centers(const int* __restrict__ clu
         int wpos = member_start[c];
         int N = 0;
         float m = 0.f;  // lane 0: x, lane 1: y, lane 2: z
-        bool hit_n = false;
-        float nx = 0.f, ny = 0.f, nz = 0.f;
-        {
-            const int i = beg + lane;
-            hit_n = (i < end) && (cluster_id[i] == c);
-            if (hit_n) { nx = off_xyz[3 * i + 0]; ny = off_xyz[3 * i + 1]; nz = off_xyz[3 * i + 2]; }
+        bool hit_n[CTR_SUB];
+        float nx[CTR_SUB], ny[CTR_SUB], nz[CTR_SUB];
+#pragma unroll
+        for (int j = 0; j < CTR_SUB; ++j) {
+            const int i = beg + j * CTR_TPB + lane;
+            hit_n[j] = (i < end) && (cluster_id[i] == c);
+            nx[j] = ny[j] = nz[j] = 0.f;
+            if (hit_n[j]) { nx[j] = off_xyz[3 * i + 0]; ny[j] = off_xyz[3 * i + 1]; nz[j] = off_xyz[3 * i + 2]; }
         }
-        for (int base = beg; base < end; base += CTR_TPB) {
-            const bool hit = hit_n;
-            const float px = nx, py = ny, pz = nz;
-            {   // prefetch the next chunk
-                const int i = base + CTR_TPB + lane;
-                hit_n = (i < end) && (cluster_id[i] == c);
-                if (hit_n) { nx = off_xyz[3 * i + 0]; ny = off_xyz[3 * i + 1]; nz = off_xyz[3 * i + 2]; }
+        for (int base = beg; base < end; base += CTR_CHUNK) {
+            bool hit[CTR_SUB];
+            float px[CTR_SUB], py[CTR_SUB], pz[CTR_SUB];
+#pragma unroll
+            for (int j = 0; j < CTR_SUB; ++j) { hit[j] = hit_n[j]; px[j] = nx[j]; py[j] = ny[j]; pz[j] = nz[j]; }
+#pragma unroll
+            for (int j = 0; j < CTR_SUB; ++j) {   // prefetch the next chunk
+                const int i = base + CTR_CHUNK + j * CTR_TPB + lane;
+                hit_n[j] = (i < end) && (cluster_id[i] == c);
+                if (hit_n[j]) { nx[j] = off_xyz[3 * i + 0]; ny[j] = off_xyz[3 * i + 1]; nz[j] = off_xyz[3 * i + 2]; }
             }
-            const unsigned long long mask = __ballot(hit);
-            const int cnt = __popcll(mask);
-            if (cnt == 0) continue;
-            const int rank = __popcll(mask & ((1ULL << lane) - 1ULL));
-            // magnitudes for which the correction-step quotient is provably exact: 0 or [1e-20, 1e20]
-            const float ax = fabsf(px), ay = fabsf(py), az = fabsf(pz);
-            const bool ok = !hit || ((ax == 0.f || (ax >= 1e-20f && ax <= 1e20f)) && (ay == 0.f || (ay >= 1e-20f && ay <= 1e20f)) &&
-                                     (az == 0.f || (az >= 1e-20f && az <= 1e20f)));
+            int cnt = 0;
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < CTR_SUB; ++j) {
+                const unsigned long long mask = __ballot(hit[j]);
+                const int rank = cnt + __popcll(mask & ((1ULL << lane) - 1ULL));
+                cnt += __popcll(mask);
+                // magnitudes for which the correction-step quotient is provably exact: 0 or [1e-20, 1e20]
+                const float ax = fabsf(px[j]), ay = fabsf(py[j]), az = fabsf(pz[j]);
+                ok = ok && (!hit[j] || ((ax == 0.f || (ax >= 1e-20f && ax <= 1e20f)) && (ay == 0.f || (ay >= 1e-20f && ay <= 1e20f)) &&
+                                        (az == 0.f || (az >= 1e-20f && az <= 1e20f))));
+                if (hit[j]) {
+                    s_xyz[0][rank] = px[j]; s_xyz[1][rank] = py[j]; s_xyz[2][rank] = pz[j];
+                    if (member_idx) member_idx[wpos + rank] = base + j * CTR_TPB + lane;
+                }
+            }
+            if (cnt == 0) continue;        // wave-uniform
             const bool fast = __all(ok);
-            if (hit) {
-                s_xyz[0][rank] = px; s_xyz[1][rank] = py; s_xyz[2][rank] = pz;
-                if (member_idx) member_idx[wpos + rank] = base + lane;
-            }
-            s_rcp[lane] = __fdiv_rn(1.0f, (float)(N + 1 + lane));  // RN(1/n) for the next 64 member counts, all lanes at once
+#pragma unroll
+            for (int j = 0; j < CTR_SUB; ++j)     // RN(1/n) for the next 256 member counts, all lanes at once
+                if (j * CTR_TPB < cnt) s_rcp[j * CTR_TPB + lane] = __fdiv_rn(1.0f, (float)(N + 1 + j * CTR_TPB + lane));
             wpos += cnt;
             __syncthreads();
             if (lane < 3) {
                 const float* v = s_xyz[lane];
                 if (fast) {
-                    int k = 0;
-                    for (; k + 4 <= cnt; k += 4) {
-                        const float v0 = v[k], v1 = v[k + 1], v2 = v[k + 2], v3 = v[k + 3];
-                        const float y0 = s_rcp[k], y1 = s_rcp[k + 1], y2 = s_rcp[k + 2], y3 = s_rcp[k + 3];
+                    // two register groups of 16 members, ping-pong: group B is read from LDS while the chain walks group A
+                    float4 va[4], ya[4], vb[4], yb[4];
+                    auto load16 = [&](float4 (&vv)[4], float4 (&yy)[4], int k) {   // reads past cnt stay inside the padded arrays
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            vv[q] = *reinterpret_cast<const float4*>(v + k + 4 * q);
+                            yy[q] = *reinterpret_cast<const float4*>(s_rcp + k + 4 * q);
+                        }
+                    };
+                    auto chain16 = [&](const float4 (&vv)[4], const float4 (&yy)[4], int k) {
                         const float n0 = (float)(N + k + 1);
-                        m = __fadd_rn(m, exact_quotient(__fsub_rn(v0, m), n0, y0));
-                        m = __fadd_rn(m, exact_quotient(__fsub_rn(v1, m), n0 + 1.0f, y1));
-                        m = __fadd_rn(m, exact_quotient(__fsub_rn(v2, m), n0 + 2.0f, y2));
-                        m = __fadd_rn(m, exact_quotient(__fsub_rn(v3, m), n0 + 3.0f, y3));
+                        const int left = cnt - k;
+                        if (left >= 16) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                m = __fadd_rn(m, exact_quotient(__fsub_rn(vv[q].x, m), n0 + (float)(4 * q + 0), yy[q].x));
+                                m = __fadd_rn(m, exact_quotient(__fsub_rn(vv[q].y, m), n0 + (float)(4 * q + 1), yy[q].y));
+                                m = __fadd_rn(m, exact_quotient(__fsub_rn(vv[q].z, m), n0 + (float)(4 * q + 2), yy[q].z));
+                                m = __fadd_rn(m, exact_quotient(__fsub_rn(vv[q].w, m), n0 + (float)(4 * q + 3), yy[q].w));
+                            }
+                        } else {
+                            for (int j = 0; j < left; ++j)      // the last group of a chunk: from LDS, one at a time
+                                m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k + j], m), n0 + (float)j, s_rcp[k + j]));
+                        }
+                    };
+                    load16(va, ya, 0);
+                    for (int k = 0; k < cnt; k += 32) {
+                        load16(vb, yb, k + 16);
+                        chain16(va, ya, k);
+                        if (k + 16 < cnt) {
+                            load16(va, ya, k + 32);
+                            chain16(vb, yb, k + 16);
+                        }
                     }
-                    for (; k < cnt; ++k)
-                        m = __fadd_rn(m, exact_quotient(__fsub_rn(v[k], m), (float)(N + k + 1), s_rcp[k]));
                 } else {
                     for (int k = 0; k < cnt; ++k) m = __fadd_rn(m, __fdiv_rn(__fsub_rn(v[k], m), (float)(N + k + 1)));
                 }
