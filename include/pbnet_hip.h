@@ -297,7 +297,10 @@ int pbn_gather_rulebook_rows(const void* in, int ld_in_bytes, int row_bytes, con
  *             not tracked) updated with `momentum` and the unbiased variance, y = (x - mean) * invstd * weight + bias
  *             (weight / bias NULL = 1 / 0).  fp32 arithmetic, sums merged in a fixed order (double for the final merge).
  *   backward: dx, dweight = sum dy * xhat, dbias = sum dy (either may be NULL).
- * workspace: pbn_bn_workspace_bytes(channels).  PBN_ERR_UNSUPPORTED when channels is not a multiple of the 16-byte
+ * workspace: pbn_bn_workspace_bytes(channels), 16-byte aligned; its FIRST 16 BYTES must be zero when a workspace is used for the
+ * first time (a ticket counter of the fused merge step -- small slabs merge their block sums in the last workgroup to
+ * finish instead of a second launch -- which every call leaves at zero again); one workspace per stream.
+ * PBN_ERR_UNSUPPORTED when channels is not a multiple of the 16-byte
  * vector width of `dtype` or a row is not 16-byte aligned (the caller then uses the framework's batch norm). */
 size_t pbn_bn_workspace_bytes(int channels);
 int pbn_bn_train_forward(const void* x, int ld_x, int n, int channels, int dtype, const float* weight, const float* bias,

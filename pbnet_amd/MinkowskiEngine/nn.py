@@ -12,9 +12,10 @@ _BN_WS = StreamScratch()
 
 
 def _bn_workspace(device, channels):
-    """Per (device, stream) scratch of the native batch norm (block partial sums), grown on demand."""
+    """Per (device, stream) scratch of the native batch norm (block partial sums), grown on demand; new blocks are zeroed (the
+    ticket counter of the fused merge step, include/pbnet_hip.h)."""
     from .. import _native as N
-    return _BN_WS.get(device, int(N.lib().pbn_bn_workspace_bytes(int(channels))), min_bytes=1 << 20)
+    return _BN_WS.get(device, int(N.lib().pbn_bn_workspace_bytes(int(channels))), min_bytes=1 << 20, zero=True)
 
 
 def _rows_ok(t):

@@ -10,6 +10,7 @@
 // masked gradient to the residual branch -- the ReLU / add passes over the slab and their launches disappear.
 #include "pbn_common.h"
 
+#include <cstdlib>
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
@@ -78,11 +79,44 @@ __device__ __forceinline__ Span span_of(int n, int vpr) {
 
 // partial[b][0][c] = sum over the block's rows of A, partial[b][1][c] = sum of B, with
 //   forward : A = x, B = x^2;   backward: A = dy, B = dy * (x - mean[c])
+// The second (merge) step of a pass, folded into the partial launch on small slabs (<= FUSE_MAX_BLOCKS partial blocks = 16 k
+// rows: the stride-4 / 8 / 16 levels, two thirds of the layers): the LAST workgroup to arrive (a ticket counter in the
+// workspace, left at zero again) merges the block partials, one thread per channel, in block order and in double -- the same
+// result whichever workgroup is last.  Saves the merge launch; an experiment, off by default (see fuse_final()).
+constexpr int FUSE_MAX_BLOCKS = 128;
+struct FinalArgs {
+    int* counter;              // nullptr: no fused merge (the separate k_bn_stats_final / k_bn_bwd_final launch follows)
+    float eps, momentum;
+    float* running_mean; float* running_var; float* save_mean; float* save_invstd;      // forward
+    const float* invstd; float* dweight; float* dbias; float* coef;                     // backward
+};
+
+__device__ __forceinline__ void stats_from_sums(double s1, double s2, int ch, int n, const float* shift, const FinalArgs& f) {
+    const double dm = s1 / n;                           // mean of (x - k)
+    const double mean = (double)shift[ch] + dm;
+    double var = s2 / n - dm * dm;                      // biased (normalisation)
+    if (var < 0.0) var = 0.0;
+    f.save_mean[ch] = (float)mean;
+    f.save_invstd[ch] = (float)(1.0 / sqrt(var + (double)f.eps));
+    if (f.running_mean) f.running_mean[ch] = (float)((1.0 - f.momentum) * f.running_mean[ch] + f.momentum * mean);
+    if (f.running_var) {
+        const double unbiased = n > 1 ? var * n / (n - 1) : var;
+        f.running_var[ch] = (float)((1.0 - f.momentum) * f.running_var[ch] + f.momentum * unbiased);
+    }
+}
+__device__ __forceinline__ void coefs_from_sums(double s1, double s2, int ch, int n, int c, const FinalArgs& f) {
+    const double is = f.invstd[ch];
+    if (f.dbias) f.dbias[ch] = (float)s1;
+    if (f.dweight) f.dweight[ch] = (float)(s2 * is);
+    f.coef[ch] = (float)(s1 / n);
+    f.coef[c + ch] = (float)(s2 * is * is / n);         // multiplies (x - mean)
+}
+
 template <typename T, bool BWD>
 __global__ __launch_bounds__(BN_TPB) void k_bn_partial(const T* __restrict__ x, int ld_x, const T* __restrict__ dy, int ld_dy,
                                                       const T* __restrict__ ymask, int ld_y,
                                                       int n, int c, const float* __restrict__ mean, float* __restrict__ partial,
-                                                      float* __restrict__ shift_out) {
+                                                      float* __restrict__ shift_out, const FinalArgs fa) {
     constexpr int W = Vec<T>::W;
     extern __shared__ float s_acc[];          // [BN_TPB][2 * W]
     const int vpr = c / W;
@@ -131,6 +165,28 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_partial(const T* __restrict__ x, 
         for (int r = 0; r < s.rows_per_iter; ++r) t += s_acc[(r * vpr + cv) * 2 * W + which * W + i];
         partial[((size_t)blockIdx.x * 2 + which) * c + ch] = t;
     }
+    if (!fa.counter) return;
+    // ---- fused merge: the last workgroup to finish ----
+    __shared__ int s_last;
+    __threadfence();                                   // this workgroup's partials (and block 0's shift) are visible device-wide ...
+    __syncthreads();                                   // ... for every thread of it, before its ticket is drawn
+    if (threadIdx.x == 0) s_last = atomicAdd(fa.counter, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                   // acquire: the other workgroups' partials
+    if (threadIdx.x == 0) *fa.counter = 0;             // ready for the next launch on this workspace (stream order)
+    const int blocks = gridDim.x;
+    const float* pin = partial;
+    for (int ch = threadIdx.x; ch < c; ch += BN_TPB) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+        for (int b = 0; b < blocks; ++b) {
+            s1 += (double)__builtin_nontemporal_load(pin + ((size_t)b * 2 + 0) * c + ch);
+            s2 += (double)__builtin_nontemporal_load(pin + ((size_t)b * 2 + 1) * c + ch);
+        }
+        if (BWD) coefs_from_sums(s1, s2, ch, n, c, fa);
+        else stats_from_sums(s1, s2, ch, n, shift_out, fa);
+    }
 }
 
 // one wave per channel: lane l sums the block partials l, l + 64, ... in double, then a fixed butterfly over the lanes
@@ -152,17 +208,10 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_stats_final(const float* __restri
     double s1, s2;
     channel_sums(partial, blocks, c, ch, s1, s2);
     if (threadIdx.x & 63) return;
-    const double dm = s1 / n;                           // mean of (x - k)
-    const double mean = (double)shift[ch] + dm;
-    double var = s2 / n - dm * dm;                      // biased (normalisation)
-    if (var < 0.0) var = 0.0;
-    save_mean[ch] = (float)mean;
-    save_invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
-    if (running_var) {
-        const double unbiased = n > 1 ? var * n / (n - 1) : var;
-        running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unbiased);
-    }
+    FinalArgs f{};
+    f.eps = eps; f.momentum = momentum; f.running_mean = running_mean; f.running_var = running_var;
+    f.save_mean = save_mean; f.save_invstd = save_invstd;
+    stats_from_sums(s1, s2, ch, n, shift, f);
 }
 
 // coef[0][c] = mean(dy), coef[1][c] = mean(dy * xhat) * invstd  (the two projections of dx), dweight, dbias
@@ -174,11 +223,9 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_bwd_final(const float* __restrict
     double s1, s2;
     channel_sums(partial, blocks, c, ch, s1, s2);
     if (threadIdx.x & 63) return;
-    const double is = invstd[ch];
-    if (dbias) dbias[ch] = (float)s1;
-    if (dweight) dweight[ch] = (float)(s2 * is);
-    coef[ch] = (float)(s1 / n);
-    coef[c + ch] = (float)(s2 * is * is / n);           // multiplies (x - mean)
+    FinalArgs f{};
+    f.invstd = invstd; f.dweight = dweight; f.dbias = dbias; f.coef = coef;
+    coefs_from_sums(s1, s2, ch, n, c, f);
 }
 
 // forward apply: y = act((x - mean) * (invstd * w) + b [+ residual]) ; backward apply: g = dy masked by (y > 0),
@@ -267,6 +314,17 @@ int apply_blocks(int n, int vpr) {
     return (int)cdiv((long long)n, (long long)rpi * iters);
 }
 
+// workspace layout: 4 ints (the merge ticket counter: at a FIXED place, layers of different widths share the workspace) |
+// [BN_MAX_BLOCKS][2][c] block partials | [2][c] shift / coefficients.  `ws` below points behind the counter.
+int* counter_of(float* ws, int c) { (void)c; return reinterpret_cast<int*>(ws - 4); }
+bool fuse_final() {
+    // OFF by default: measured on the configs[2] step (round 4), the last workgroup's tail -- fence, ticket, acquire, merge, double
+    // division / square root, all on one latency chain -- adds 8.5 us to a fused partial launch where the separate merge
+    // launch costs 5: 17.5 -> 21.2 ms of batch-norm kernels per 4 steps, step time level (31.7 ms both ways, 220 launches fewer)
+    static const bool on = getenv("PBN_BN_FUSE_FINAL") && atoi(getenv("PBN_BN_FUSE_FINAL")) == 1;
+    return on;
+}
+
 int blocks_for(int n) {
     int b = (n + 127) / 128;
     return b < 1 ? 1 : (b > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : b);
@@ -286,12 +344,20 @@ int forward_t(const void* x, int ld_x, int n, int c, const float* weight, const 
         return PBN_ERR_UNSUPPORTED;
     constexpr int W = Vec<T>::W;
     const int blocks = blocks_for(n);
+    FinalArgs fa{};
+    const bool fuse = fuse_final() && blocks <= FUSE_MAX_BLOCKS;
+    if (fuse) {
+        fa.counter = counter_of(ws, c);
+        fa.eps = eps; fa.momentum = momentum; fa.running_mean = running_mean; fa.running_var = running_var;
+        fa.save_mean = save_mean; fa.save_invstd = save_invstd;
+    }
     hipLaunchKernelGGL((k_bn_partial<T, false>), dim3(blocks), dim3(BN_TPB), BN_TPB * 2 * W * sizeof(float), stream, (const T*)x,
                        ld_x, (const T*)nullptr, 0, (const T*)nullptr, 0, n, c, (const float*)nullptr, ws,
-                       ws + (size_t)BN_MAX_BLOCKS * 2 * c);
-    hipLaunchKernelGGL(k_bn_stats_final, dim3(cdiv(c, BN_TPB / 64)), dim3(BN_TPB), 0, stream, ws,
-                       ws + (size_t)BN_MAX_BLOCKS * 2 * c, blocks, n, c, eps, momentum,
-                       running_mean, running_var, save_mean, save_invstd);
+                       ws + (size_t)BN_MAX_BLOCKS * 2 * c, fa);
+    if (!fuse)
+        hipLaunchKernelGGL(k_bn_stats_final, dim3(cdiv(c, BN_TPB / 64)), dim3(BN_TPB), 0, stream, ws,
+                           ws + (size_t)BN_MAX_BLOCKS * 2 * c, blocks, n, c, eps, momentum,
+                           running_mean, running_var, save_mean, save_invstd);
     hipLaunchKernelGGL((k_bn_apply<T, false>), dim3(apply_blocks(n, c / W)), dim3(BN_TPB), 0, stream, (const T*)x, ld_x,
                        (const T*)nullptr, 0, n, c, save_mean, save_invstd, weight, bias, (const float*)nullptr, (T*)y, ld_y,
                        (const T*)residual, ld_res, relu, (T*)nullptr, 0);
@@ -309,10 +375,17 @@ int backward_t(const void* x, int ld_x, const void* dy, int ld_dy, const void* y
     constexpr int W = Vec<T>::W;
     const int blocks = blocks_for(n);
     float* coef = ws + (size_t)BN_MAX_BLOCKS * 2 * c;
+    FinalArgs fa{};
+    const bool fuse = fuse_final() && blocks <= FUSE_MAX_BLOCKS;
+    if (fuse) {
+        fa.counter = counter_of(ws, c);
+        fa.invstd = save_invstd; fa.dweight = dweight; fa.dbias = dbias; fa.coef = coef;
+    }
     hipLaunchKernelGGL((k_bn_partial<T, true>), dim3(blocks), dim3(BN_TPB), BN_TPB * 2 * W * sizeof(float), stream, (const T*)x,
-                       ld_x, (const T*)dy, ld_dy, (const T*)y, ld_y, n, c, save_mean, ws, (float*)nullptr);
-    hipLaunchKernelGGL(k_bn_bwd_final, dim3(cdiv(c, BN_TPB / 64)), dim3(BN_TPB), 0, stream, ws, blocks, n, c, save_invstd, dweight,
-                       dbias, coef);
+                       ld_x, (const T*)dy, ld_dy, (const T*)y, ld_y, n, c, save_mean, ws, (float*)nullptr, fa);
+    if (!fuse)
+        hipLaunchKernelGGL(k_bn_bwd_final, dim3(cdiv(c, BN_TPB / 64)), dim3(BN_TPB), 0, stream, ws, blocks, n, c, save_invstd,
+                           dweight, dbias, coef);
     hipLaunchKernelGGL((k_bn_apply<T, true>), dim3(apply_blocks(n, c / W)), dim3(BN_TPB), 0, stream, (const T*)x, ld_x,
                        (const T*)dy, ld_dy, n, c, save_mean, save_invstd, weight, (const float*)nullptr, coef, (T*)dx, ld_dx,
                        (const T*)y, ld_y, 0, (T*)dres, ld_dres);
@@ -326,7 +399,7 @@ int backward_t(const void* x, int ld_x, const void* dy, int ld_dy, const void* y
 using namespace pbn;
 
 extern "C" size_t pbn_bn_workspace_bytes(int channels) {
-    return channels > 0 ? sizeof(float) * ((size_t)BN_MAX_BLOCKS * 2 * channels + 2 * (size_t)channels) : 0;
+    return channels > 0 ? sizeof(float) * ((size_t)BN_MAX_BLOCKS * 2 * channels + 2 * (size_t)channels) + 16 : 0;
 }
 
 extern "C" int pbn_bn_act_train_forward(const void* x, int ld_x, int n, int channels, int dtype, const float* weight,
@@ -336,7 +409,7 @@ extern "C" int pbn_bn_act_train_forward(const void* x, int ld_x, int n, int chan
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 1 || channels < 1 || !save_mean || !save_invstd) return PBN_ERR_ARG;
     if (!workspace || workspace_bytes < pbn_bn_workspace_bytes(channels) || ((uintptr_t)workspace & 15)) return PBN_ERR_WORKSPACE;
-    float* ws = (float*)workspace;
+    float* ws = (float*)workspace + 4;
     switch (dtype) {
         case PBN_F32: return forward_t<float>(x, ld_x, n, channels, weight, bias, eps, momentum, running_mean, running_var,
                                               residual, ld_res, relu, y, ld_y, save_mean, save_invstd, ws, stream);
@@ -364,7 +437,7 @@ extern "C" int pbn_bn_act_train_backward(const void* x, int ld_x, const void* dy
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 1 || channels < 1 || !save_mean || !save_invstd) return PBN_ERR_ARG;
     if (!workspace || workspace_bytes < pbn_bn_workspace_bytes(channels) || ((uintptr_t)workspace & 15)) return PBN_ERR_WORKSPACE;
-    float* ws = (float*)workspace;
+    float* ws = (float*)workspace + 4;
     switch (dtype) {
         case PBN_F32: return backward_t<float>(x, ld_x, dy, ld_dy, y, ld_y, n, channels, weight, save_mean, save_invstd, dx, ld_dx,
                                                dres, ld_dres, dweight, dbias, ws, stream);
