@@ -193,7 +193,19 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_partial(const T* __restrict__ x, 
 __device__ __forceinline__ void channel_sums(const float* __restrict__ partial, int blocks, int c, int ch, double& s1, double& s2) {
     const int lane = threadIdx.x & 63;
     s1 = 0.0; s2 = 0.0;
-    for (int b = lane; b < blocks; b += 64) { s1 += partial[((size_t)b * 2 + 0) * c + ch]; s2 += partial[((size_t)b * 2 + 1) * c + ch]; }
+    // loads four block steps ahead of the (ordered) double additions: the merge is one latency chain per channel otherwise
+    int b = lane;
+    for (; b + 192 < blocks; b += 256) {
+        float p0[4], p1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            p0[u] = partial[((size_t)(b + 64 * u) * 2 + 0) * c + ch];
+            p1[u] = partial[((size_t)(b + 64 * u) * 2 + 1) * c + ch];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s1 += p0[u]; s2 += p1[u]; }
+    }
+    for (; b < blocks; b += 64) { s1 += partial[((size_t)b * 2 + 0) * c + ch]; s2 += partial[((size_t)b * 2 + 1) * c + ch]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
 }

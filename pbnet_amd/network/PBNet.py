@@ -12,6 +12,8 @@ What differs is WHERE things run, not what is computed:
   * get_proposal (PBNet.py:317-347) is a device compaction instead of Python loops.
 One host synchronisation per stage boundary (class counts, cluster table, proposal count), none per class/cluster.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -27,6 +29,8 @@ COUNT_MEAN = [-1., -1., 3917., 12056., 2303., 8331., 3948., 3166., 5629., 11719.
 LOCAL_VOXEL = 0.02                                                    # PBNet.py:236 (hard-coded)
 HEAD_CLUSTERS = 256                                                   # clusters whose centres travel with the first grouping read-back
 MASK_THD = 0.45                                                       # PBNet.py:317
+# training: index-only glue between the networks on the inference path's fused launches (see PBNet.forward); "0" = plain torch
+TRAIN_FUSED_GLUE = os.environ.get("PBNET_TRAIN_FUSED_GLUE", "1") == "1"
 
 
 def _mlp(cin, mid, cout, sigmoid=False):
@@ -94,6 +98,17 @@ class PBNet(nn.Module):
             nb = self.batch_size if task == "train" else 3                          # PBNet.py:167-170
             stage1["sem_pred_p"], stage1["sem_prob_p"], stage1["table"], stage1["block_hist"] = \
                 stage_ops.sem_argmax_table(stage1["sem_pred_score_p"], stage1["batch_head_p"], nb)
+        elif TRAIN_FUSED_GLUE and stage1["sem_pred_score_p"].is_cuda and epoch > self.cluster_epoch:
+            # training: everything between the networks that carries NO gradient (argmax, population table, class-major
+            # selection, the rows of the local scenes, proposal rows) runs as the inference path's fused launches, under
+            # no_grad; what gradients flow through (features gathered at those rows, the softmax scores) stays torch.
+            # The same integers either way (tests/test_train_gpu.py); ~70 small launches fewer per step, in the part of the
+            # forward where the GPU waits for the host.
+            nb = self.batch_size if task == "train" else 3
+            with torch.no_grad():
+                sc = stage1["sem_pred_score_p"].detach()
+                stage1["sem_pred_p"], _, stage1["table"], stage1["block_hist"] = stage_ops.sem_argmax_table(
+                    sc if sc.stride(1) == 1 else sc.contiguous(), stage1["batch_head_p"].to(torch.int32).contiguous(), nb)
         ret = {"sem_pred_p": stage1["sem_pred_p"], "sem_pred_score_p": stage1["sem_pred_score_p"],
                "offset_pred_p": stage1["offset_pred_p"]}
         if epoch > self.cluster_epoch:
@@ -147,7 +162,8 @@ class PBNet(nn.Module):
         fused_glue = not torch.is_grad_enabled()      # inference: stage glue as fused launches (stage_ops)
         sem_pred_p = s1["sem_pred_p"]
         point_feat_p, offset_pred_p = s1["point_feat_p"], s1["offset_pred_p"]
-        sem_sfp = s1["sem_prob_p"].view(-1, 1) if fused else s1["sem_pred_score_sfp"]
+        train_glue = fused and torch.is_grad_enabled()       # fused index work, differentiable features (see forward())
+        sem_sfp = s1["sem_prob_p"].view(-1, 1) if (fused and not train_glue) else s1["sem_pred_score_sfp"]
         self.cluster_batch = self.batch_size if task == "train" else 3          # PBNet.py:167-170
         nb = self.cluster_batch
         n_cls = int(self.sem_num)
@@ -180,8 +196,9 @@ class PBNet(nn.Module):
                 run += per_class[c]
             up = torch.from_numpy(np.concatenate([class_base, seg_len_h])).to(dev)
             seg_len = up[n_cls:]
-            ins_ind, ins_orig, ins_offseted, ins_sem = stage_ops.select_points(
-                sem_pred_p, up[:n_cls], s1["block_hist"], xyz_original, offset_pred_p, m)
+            with torch.no_grad():
+                ins_ind, ins_orig, ins_offseted, ins_sem = stage_ops.select_points(
+                    sem_pred_p, up[:n_cls], s1["block_hist"], xyz_original, offset_pred_p.detach(), m)
         else:
             keep = torch.zeros(n_cls, dtype=torch.bool)
             keep[classes] = True
@@ -194,7 +211,7 @@ class PBNet(nn.Module):
             seg_len = torch.from_numpy(seg_len_h).to(dev)
         _sec.__exit__(None, None, None)
 
-        if fused:
+        if fused and not train_glue:
             self._last_sizes["points"] = int(m)
         mark("a7:select queued")
         with section("a7_16_grouping"):
@@ -269,7 +286,7 @@ class PBNet(nn.Module):
         # device gathers over points: rows of every local scene, in the reference's order
         _sec = section("a17_gather"); _sec.__enter__()
         ent_np = np.asarray(ent_cluster, dtype=np.int64)
-        if not torch.is_grad_enabled():
+        if not torch.is_grad_enabled() or train_glue:
             # inference: ONE launch (pbn_local_scene_rows) driven by one packed host->device copy of the entry table
             n_ent = len(ent_cluster)
             row_start = np.zeros(n_ent + 1, dtype=np.int32)
@@ -278,10 +295,16 @@ class PBNet(nn.Module):
             ent_scene = np.repeat(np.arange(len(scene_len), dtype=np.int32), scene_len)
             packed = torch.from_numpy(np.concatenate([row_start, member_start[:-1][ent_np].astype(np.int32), ent_scene,
                                                       np.asarray(ent_weight, dtype=np.float32).view(np.int32)])).to(dev)
-            point_idx, row_scene, coords, feat = stage_ops.local_scene_rows(
-                packed, n_ent, n_rows, res.member_idx, ins_ind, xyz_original, LOCAL_VOXEL, point_feat_p, sem_sfp,
-                None if fused else sem_pred_p)
-            if fused:
+            with torch.no_grad():
+                point_idx, row_scene, coords, feat = stage_ops.local_scene_rows(
+                    packed, n_ent, n_rows, res.member_idx, ins_ind, xyz_original, LOCAL_VOXEL, point_feat_p.detach(),
+                    sem_sfp.detach(), None if (fused and not train_glue) else sem_pred_p)
+            if train_glue:
+                # the same rows with their gradients: features and own-class scores gathered by torch, the entry weight (a
+                # constant) taken from the fused launch's last column                                  PBNet.py:162-163,194,230
+                row_sem_sf = sem_sfp[point_idx, sem_pred_p[point_idx]]
+                feat = torch.cat([point_feat_p[point_idx], row_sem_sf.view(-1, 1).to(point_feat_p.dtype), feat[:, -1:]], 1)
+            elif fused:
                 self._last_sizes.update(clusters=int(n_clt), entries=int(n_ent), rows=int(n_rows))
         else:
             ent_cluster_t = torch.from_numpy(ent_np)
@@ -329,6 +352,11 @@ class PBNet(nn.Module):
             if fused_glue:
                 out["proposals"], coords3, feat3 = self._proposals_fused(row_scene, point_idx, mask_score, len(scene_len),
                                                                          xyz_original, point_feat_p)
+            elif train_glue:
+                with torch.no_grad():
+                    out["proposals"], coords3, _ = self._proposals_fused(row_scene, point_idx, mask_score.detach(), len(scene_len),
+                                                                         xyz_original, point_feat_p.detach())
+                feat3 = point_feat_p[out["proposals"][0][:, 1]]
             else:
                 out["proposals"] = self.get_proposal(row_scene, point_idx, mask_score, n_scenes=len(scene_len))
 
@@ -499,10 +527,13 @@ def model_fn(batch, model, epoch, cfg, task="train"):
                                                        xyz_original.float(), epoch, cfg)
     with torch.no_grad():
         pred = {"sem": sem_pred_p, "offseted_xyz": xyz_original + offset_pred_p}
-        visual_dict = {k: parts[k].item() for k in ("loss", "semantic_loss", "offset_norm_loss", "offset_dir_loss")}
+        # the logged terms in ONE read-back (the reference calls .item() per term: five synchronisations)
+        names = ["loss", "semantic_loss", "offset_norm_loss", "offset_dir_loss"] + (["mask_loss"] if epoch > cfg.cluster_epoch else [])
+        host = torch.stack([parts[k].detach().float().reshape(()) for k in names]).tolist()
+        visual_dict = dict(zip(names[:4], host[:4]))
         meter_dict = {k: (v, valid.sum()) for k, v in visual_dict.items()}
         if epoch > cfg.cluster_epoch:
-            visual_dict["mask_loss"] = parts["mask_loss"].item()
+            visual_dict["mask_loss"] = host[4]
             meter_dict["mask_loss"] = (visual_dict["mask_loss"], weight.sum())
             pred["mask_scores"] = ret["mask_scores"]               # carries the mutated gt_mask, as upstream
             pred["proposals"] = ret["proposals"]

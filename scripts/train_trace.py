@@ -34,6 +34,24 @@ def main():
             j += 1
         print("%5d x%-3d %8.1f us  %s" % (i, j - i, sum(dur[i:j]), seq[i]))
         i = j
+    # where the GPU waits for the host: gaps between the end of one kernel and the start of the next (single stream)
+    st = [int(r["Start_Timestamp"]) for r in rows[a:b]]
+    en = [int(r["End_Timestamp"]) for r in rows[a:b]]
+    gaps, hi = [], en[0]
+    for j in range(1, len(st)):
+        if st[j] > hi:
+            gaps.append(((st[j] - hi) / 1e3, j))
+        hi = max(hi, en[j])
+    print("---- idle: %.2f ms in %d gaps; > 20 us: %.2f ms in %d; > 100 us: %.2f ms in %d" % (
+        sum(g for g, _ in gaps) / 1e3, len(gaps), sum(g for g, _ in gaps if g > 20) / 1e3, sum(1 for g, _ in gaps if g > 20),
+        sum(g for g, _ in gaps if g > 100) / 1e3, sum(1 for g, _ in gaps if g > 100)))
+    # idle by 100-launch window (which part of the step is host-bound)
+    for w0 in range(0, len(seq), 100):
+        gw = sum(g for g, j in gaps if w0 <= j < w0 + 100)
+        kw = sum(dur[w0:w0 + 100])
+        print("  launches %4d-%4d: kernels %7.1f us, idle %7.1f us   first: %s" % (w0, min(w0 + 100, len(seq)) - 1, kw, gw, seq[w0]))
+    for g, j in sorted(gaps, reverse=True)[:25]:
+        print("  gap %7.1f us before launch %4d %s (after %s)" % (g, j, seq[j], seq[j - 1]))
     print("---- counts")
     cnt, tot = Counter(seq), Counter()
     for n, d in zip(seq, dur):
