@@ -129,8 +129,12 @@ __device__ __forceinline__ TileMap map_block(const ConvArgs& a, int n_row_tiles,
     return m;
 }
 
-template <typename T, int NF, int NT, int KW, bool KSPLIT>
+// KLIST (K-split only, round 4): the workgroup's waves take the POPULATED steps of the tile round-robin (every wave builds the same
+// list; wave w consumes entries w, w + KW, ...) instead of every step -- for the k = 5 stems, where a 32-row tile has a
+// neighbour at 30-40 % of the 125 offsets (the coarse levels, 93-98 % populated, keep the computed steps: no list to build).
+template <typename T, int NF, int NT, int KW, bool KSPLIT, bool KLIST = false>
 __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
+    static_assert(!KLIST || KSPLIT, "the shared step list is a K-split feature");
     static_assert(Tr<T>::ELEMS * sizeof(T) == 16, "one gather vector is 16 bytes");
     constexpr int RW = NF * 16;                          // rows per wave
     constexpr int TM = KSPLIT ? RW : KW * RW;            // rows per workgroup
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     // row-split: per-wave unit lists; K-split: units are computed (every step is visited), the space holds the epilogue
     // constants (scale | shift of this workgroup's NT*16 channels) and the reduction buffer
     unsigned* s_units = reinterpret_cast<unsigned*>(s_nbr + ((TM * KS + 3) & ~3));    // row-split: KW * (n_steps + 2 * MAX_DEPTH)
-    const int units_pitch = KSPLIT ? 0 : a.n_steps + 2 * MAX_DEPTH;
+    const int units_pitch = (KSPLIT && !KLIST) ? 0 : a.n_steps + 2 * MAX_DEPTH + (KLIST ? 64 : 0);
     int* s_none = reinterpret_cast<int*>(s_units + ((KW * units_pitch + 3) & ~3));    // one word, -1: "no neighbour" for units past the end
     float* s_ss = reinterpret_cast<float*>(s_none + 4);                               // K-split: 2 * NT*16 floats
     float* s_red = s_ss + 2 * NT * 16;                                                // K-split: KW * TM * NTB*16 floats
@@ -188,7 +192,8 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     // step of this wave's unit i (>= n_steps: past the end, the unit adds zeros).  K-split: every step is visited, wave w
     // takes steps w, w + KW, ...; row-split: the wave's list of populated steps in LDS
     auto step_of = [&](int i) -> int {
-        if constexpr (KSPLIT) return i * KW + wave;
+        if constexpr (KLIST) return __builtin_amdgcn_readfirstlane((int)my_units[i * KW + wave]);
+        else if constexpr (KSPLIT) return i * KW + wave;
         else return __builtin_amdgcn_readfirstlane((int)my_units[i]);
     };
     // the loads of one unit, branch-free (a branch in the loop body makes hipcc's wait-count insertion drain the queue at
@@ -247,18 +252,19 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
 
     const int wrow0 = KSPLIT ? 0 : wave * RW;
     int n_units;
-    if constexpr (KSPLIT) {
+    if constexpr (KSPLIT && !KLIST) {
         // coarse levels: 93-98 % of the (64-row tile, offset) pairs are populated (scripts/analyze_rulebook.py) -- visiting
         // every step costs a few per cent of MFMA work and takes the population scan and the unit list out of the prologue
         // of a launch whose whole main loop is a few microseconds
         n_units = a.n_steps > wave ? (a.n_steps - wave + KW - 1) / KW : 0;
     } else {
-        // ---- which offsets are populated among this wave's rows (K <= 128: two ballots) ----
+        // ---- which offsets are populated among this wave's rows / the tile's rows (K <= 128: two ballots) ----
+        constexpr int SCAN = KSPLIT ? TM : RW;
         bool any0 = false, any1 = false;
         if (lane < K)
-            for (int r = 0; r < RW; ++r) any0 |= s_nbr[(wrow0 + r) * KS + lane] >= 0;
+            for (int r = 0; r < SCAN; ++r) any0 |= s_nbr[(wrow0 + r) * KS + lane] >= 0;
         if (64 + lane < K)
-            for (int r = 0; r < RW; ++r) any1 |= s_nbr[(wrow0 + r) * KS + 64 + lane] >= 0;
+            for (int r = 0; r < SCAN; ++r) any1 |= s_nbr[(wrow0 + r) * KS + 64 + lane] >= 0;
         const unsigned long long pop0 = __ballot(any0), pop1 = __ballot(any1);
         auto populated = [&](int k) -> bool { return ((k < 64 ? pop0 >> k : pop1 >> (k - 64)) & 1ull) != 0ull; };
         // ---- this wave's unit list: populated steps, in order ----
@@ -284,9 +290,12 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
             if (ok) my_units[base + __popcll(m & ((1ULL << lane) - 1ULL))] = (unsigned)s;
             base += __popcll(m);
         }
-        n_units = base;
         // sentinels: the pipeline below always has B units in flight and needs no tail handling
-        if (lane < 2 * B + 2) my_units[n_units + lane] = UNIT_NONE;   // steps past the end
+        constexpr int NSENT = (2 * B + 2) * (KLIST ? KW : 1);
+        static_assert(NSENT <= 64, "one store per lane writes the sentinels");
+        if (lane < NSENT) my_units[base + lane] = UNIT_NONE;   // steps past the end
+        if constexpr (KLIST) n_units = base > wave ? (base - wave + KW - 1) / KW : 0;   // this wave's share of the tile's list
+        else n_units = base;
         // the list is wave-private and a wave's LDS operations execute in order: the reads below follow the writes above
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -384,11 +393,15 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
         int step = step_of(0);
         Idx ix = fetch_idx(step);
         int raw_next = 0;
-        if constexpr (!KSPLIT) raw_next = (int)my_units[1];
+        if constexpr (KLIST) raw_next = (int)my_units[KW + wave];
+        else if constexpr (!KSPLIT) raw_next = (int)my_units[1];
         auto slot = [&](Stage<NF, NT>& u, int k) {
             issue_w(u, step);
             issue_x(u, ix);
-            if constexpr (KSPLIT) {
+            if constexpr (KLIST) {
+                step = __builtin_amdgcn_readfirstlane(raw_next);
+                raw_next = (int)my_units[(k + 2) * KW + wave];
+            } else if constexpr (KSPLIT) {
                 step = step_of(k + 1);
             } else {
                 step = __builtin_amdgcn_readfirstlane(raw_next);
@@ -484,7 +497,7 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     PBN_WSTAMP(6);
 }
 
-template <typename T, int NF, int NT, int KW, bool KSPLIT>
+template <typename T, int NF, int NT, int KW, bool KSPLIT, bool KLIST = false>
 int launch_cfg(ConvArgs a, hipStream_t stream) {
     constexpr int RW = NF * 16;
     constexpr int TM = KSPLIT ? RW : KW * RW;
@@ -493,9 +506,9 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
     const int KS = a.K | 1;
     size_t lds = sizeof(int) * (size_t)((TM * KS + 3) & ~3);
     if (KSPLIT) lds += 16 + sizeof(float) * ((size_t)2 * NT * 16 + (size_t)KW * TM * ksplit_red_pitch(NTB));
-    else lds += 16 + sizeof(unsigned) * (size_t)((KW * (a.n_steps + 2 * MAX_DEPTH) + 3) & ~3);
+    if (!KSPLIT || KLIST) lds += (KSPLIT ? 0 : 16) + sizeof(unsigned) * (size_t)((KW * (a.n_steps + 2 * MAX_DEPTH + (KLIST ? 64 : 0)) + 3) & ~3);
     if (lds > 160 * 1024 || a.K > 128 || a.n_steps > 0xfffe) return PBN_ERR_UNSUPPORTED;
-    auto kern = k_spconv_wave<T, NF, NT, KW, KSPLIT>;
+    auto kern = k_spconv_wave<T, NF, NT, KW, KSPLIT, KLIST>;
     if (lds > 64 * 1024)
         PBN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int row_tiles = cdiv(a.n_out, TM), groups = a.ntiles_total / NT;
@@ -510,7 +523,7 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
     return PBN_OK;
 }
 
-// cfg = 1000 * ksplit + 100 * NF + NT
+// cfg = 1000 * ksplit (2000: K-split with the populated-step list) + 100 * NF + NT
 template <typename T>
 int launch_by_cfg(const ConvArgs& a, int cfg, hipStream_t stream) {
     switch (cfg) {
@@ -530,6 +543,8 @@ int launch_by_cfg(const ConvArgs& a, int cfg, hipStream_t stream) {
         case 1204: return launch_cfg<T, 2, 4, 8, true>(a, stream);
         case 1208: return launch_cfg<T, 2, 8, 8, true>(a, stream);
         case 1408: return launch_cfg<T, 4, 8, 8, true>(a, stream);
+        case 2202: return launch_cfg<T, 2, 2, 8, true, true>(a, stream);      // K-split over the tile's populated steps
+        case 2201: return launch_cfg<T, 2, 1, 8, true, true>(a, stream);
         default: return PBN_ERR_UNSUPPORTED;
     }
 }
@@ -546,7 +561,11 @@ int pick_cfg(const ConvArgs& a) {
     // the k = 5 stems of the local-scene networks (32 / 64-byte... 64 / 128-byte input rows, 125 offsets, 58 k rows): the same
     // shape wins there (round 4, scripts/probe_halo.py: 146 k rows 32->32 152 -> 90 us, 64->32 179 -> 156 against the
     // workgroup-tile kernel, whose 125-column rulebook tile leaves it two workgroups per CU)
-    if (a.vpo <= 8 && a.K >= 64 && ntt % 2 == 0) return 1202;
+    // round 4: their K-split over the tile's POPULATED steps (KLIST, 2202): 146 k-row probe 40->32 170 -> 154 us; level on 32->32
+    // (94 / 95) and a loss on the 16-byte-row stem above, where a step spans four offsets and nearly every step is populated
+    // (41 -> 65 us: the list costs more than the few steps it drops) -- so only rows of 4+ vectors take it
+    static const int klist = getenv("PBN_WAVE_KLIST") ? atoi(getenv("PBN_WAVE_KLIST")) : 1;
+    if (a.vpo <= 8 && a.K >= 64 && ntt % 2 == 0) return (klist && a.vpo >= 8) ? 2202 : 1202;
     int best = 0;
     long long best_wgs = -1;
     for (int cfg : {1404, 1204, 1402, 1202, 1401, 1201}) {

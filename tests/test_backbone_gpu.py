@@ -391,7 +391,7 @@ def test_unet_forward_is_graph_capturable_fp16(golden_dir):
     assert ((out.float().cpu() - want).norm() / want.norm()).item() < 5e-3
 
 
-WAVE_CFGS = (401, 402, 404, 406, 408, 204, 206, 208, 1401, 1402, 1404, 1201, 1202, 1204)
+WAVE_CFGS = (401, 402, 404, 406, 408, 204, 206, 208, 1401, 1402, 1404, 1201, 1202, 1204, 2201, 2202)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL), (torch.bfloat16, 6e-2), (torch.float16, 1e-2)])
@@ -469,7 +469,7 @@ def test_shortcut_folded_into_the_second_convolution(dtype, tol, cin, cin2, cout
     shift = _pad_vec((b2 + bd).to(DEV), cout_p, 0.0)
     lim = tol if dtype == torch.float32 else tol * max(1.0, want.abs().max().item())
     ran = 0
-    for cfg in (0, 16, 32, 64, 401, 402, 404, 406, 408, 204, 206, 208, 1401, 1402, 1404, 1201, 1202, 1204, 1208):
+    for cfg in (0, 16, 32, 64, 401, 402, 404, 406, 408, 204, 206, 208, 1401, 1402, 1404, 1201, 1202, 1204, 1208, 2201, 2202):
         if cfg >= 100 and (cout_p // 16) % (cfg % 100):
             continue
         try:
