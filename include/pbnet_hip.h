@@ -374,6 +374,13 @@ int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g, int dtype
                      const int32_t* out_idx, const int32_t* seg_begin, const int32_t* pair_counts, int segment,
                      int n_pairs_total, int n_offsets, int cin, int cout, float* dw, void* workspace, size_t workspace_bytes,
                      pbn_stream_t stream);
+/* The same with the caller's row counts: PBN_ERR_RANGE when a slab reaches 4 GiB (the kernels address rows with 32-bit byte
+ * offsets) or the lists 2^30 pairs, PBN_ERR_ARG for device-built (unpadded) lists without pair_counts unless the caller declares
+ * them padded (pbn_rulebook_pair_fill pads with -1), or for more identity pairs than rows.  What the package itself calls. */
+int pbn_spconv_wgrad_checked(const void* x, int ld_x, long long n_x_rows, const void* g, int ld_g, long long n_g_rows, int dtype,
+                             const int32_t* in_idx, const int32_t* out_idx, const int32_t* seg_begin, const int32_t* pair_counts,
+                             int lists_padded, int segment, int n_pairs_total, int n_offsets, int cin, int cout, float* dw,
+                             void* workspace, size_t workspace_bytes, pbn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Capacity-planned inference (csrc/plan.hip): the data-dependent sizes of PBNet.forward stay on the device.  Every buffer

@@ -451,11 +451,11 @@ def wgrad_native(feats, grad_out, nbr, cin, cout):
         n_pairs = max(WGRAD_PAIR_SEGMENT, (int(nbr.shape[0]) * k) // (2 if k >= 27 else 4))
     dw = torch.empty(k, cin, cout, dtype=torch.float32, device=dev)
     ws = _WGRAD_WS.get(dev, int(lib.pbn_spconv_wgrad_workspace_bytes(k, cin, cout)))
-    rc = lib.pbn_spconv_wgrad(N.c_vp(feats.data_ptr()), feats.stride(0), N.c_vp(grad_out.data_ptr()), grad_out.stride(0),
-                              _DT[feats.dtype], N.ptr(in_idx), N.ptr(out_idx), N.ptr(seg_begin), N.ptr(counts),
-                              WGRAD_PAIR_SEGMENT if nbr is not None else 0, n_pairs, k, int(cin), int(cout), N.ptr(dw),
-                              N.c_vp(ws.data_ptr()), ws.numel(), N.current_stream())
-    N.check(rc, "pbn_spconv_wgrad")
+    rc = lib.pbn_spconv_wgrad_checked(N.c_vp(feats.data_ptr()), feats.stride(0), int(feats.shape[0]), N.c_vp(grad_out.data_ptr()),
+                                      grad_out.stride(0), int(grad_out.shape[0]), _DT[feats.dtype], N.ptr(in_idx), N.ptr(out_idx),
+                                      N.ptr(seg_begin), N.ptr(counts), 0, WGRAD_PAIR_SEGMENT if nbr is not None else 0, n_pairs, k,
+                                      int(cin), int(cout), N.ptr(dw), N.c_vp(ws.data_ptr()), ws.numel(), N.current_stream())
+    N.check(rc, "pbn_spconv_wgrad_checked")
     return dw
 
 

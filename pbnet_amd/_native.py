@@ -126,6 +126,8 @@ SIGNATURES = {
     "pbn_spconv_wgrad_workspace_bytes": (c_size, [c_int, c_int, c_int]),
     "pbn_spconv_wgrad": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_int,
                                  c_f32p, c_vp, c_size, c_vp]),
+    "pbn_spconv_wgrad_checked": (c_int, [c_vp, c_int, ctypes.c_longlong, c_vp, c_int, ctypes.c_longlong, c_int, c_vp, c_vp, c_i32p,
+                                         c_i32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_vp, c_size, c_vp]),
     "pbn_gather_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "pbn_segment_pool_workspace_bytes": (c_size, [c_int, c_int]),
     "pbn_segment_pool": (c_int, [c_vp, c_int, c_int, c_int, c_i32p, c_int, c_f32p, c_f32p, c_vp, c_size, c_vp]),

@@ -122,14 +122,15 @@ extern "C" int pbn_unet_train_backward(const pbn_train_op* ops, int n_ops, const
         // 3. weight gradient over the rule pairs of the forward map
         const void* x = act(o.in_buf) + (size_t)o.in_col * es;
         if (o.map_kind == 0) {
-            rc = pbn_spconv_wgrad(x, ld(o.in_buf), gpre, ldg(o.pre_buf), dtype, nullptr, nullptr, nullptr, nullptr, 0, n_out, 1,
-                                  o.cin, o.cout, param_grads + o.dw_off, wgrad_ws, wgrad_ws_bytes, stream);
+            rc = pbn_spconv_wgrad_checked(x, ld(o.in_buf), n_in, gpre, ldg(o.pre_buf), n_out, dtype, nullptr, nullptr, nullptr,
+                                          nullptr, 0, 0, n_out, 1, o.cin, o.cout, param_grads + o.dw_off, wgrad_ws, wgrad_ws_bytes,
+                                          stream);
         } else {
             const pbn_pair_lists& P = pairs[slot];
             if (!P.in_idx || !P.out_idx || !P.seg_begin) return PBN_ERR_ARG;
-            rc = pbn_spconv_wgrad(x, ld(o.in_buf), gpre, ldg(o.pre_buf), dtype, P.in_idx, P.out_idx, P.seg_begin, P.counts,
-                                  P.segment, P.n_pairs_estimate, K, o.cin, o.cout, param_grads + o.dw_off, wgrad_ws,
-                                  wgrad_ws_bytes, stream);
+            rc = pbn_spconv_wgrad_checked(x, ld(o.in_buf), n_in, gpre, ldg(o.pre_buf), n_out, dtype, P.in_idx, P.out_idx,
+                                          P.seg_begin, P.counts, 0, P.segment, P.n_pairs_estimate, K, o.cin, o.cout,
+                                          param_grads + o.dw_off, wgrad_ws, wgrad_ws_bytes, stream);
         }
         if (rc != PBN_OK) return rc;
     }

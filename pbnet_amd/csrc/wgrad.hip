@@ -689,3 +689,20 @@ extern "C" int pbn_spconv_wgrad(const void* x, int ld_x, const void* g, int ld_g
     PBN_LAUNCH_CHECK();
     return PBN_OK;
 }
+
+// The same launch behind the checks its 32-bit buffer offsets rely on (the raw entry above takes no row counts): a slab of
+// 4 GiB or more would wrap `row * ld * esize`, pair lists of 2^30 entries `index * 4`; device-built lists (pbn_rulebook_pair_fill_dev /
+// pairs_multi) are NOT -1 padded, so walking them without their pair counts reads whatever lies behind the last pair.
+extern "C" int pbn_spconv_wgrad_checked(const void* x, int ld_x, long long n_x_rows, const void* g, int ld_g, long long n_g_rows,
+                                        int dtype, const int32_t* in_idx, const int32_t* out_idx, const int32_t* seg_begin,
+                                        const int32_t* pair_counts, int lists_padded, int segment, int n_pairs_total, int n_offsets,
+                                        int cin, int cout, float* dw, void* workspace, size_t workspace_bytes, pbn_stream_t stream) {
+    if (n_x_rows < 0 || n_g_rows < 0 || ld_x < 1 || ld_g < 1) return PBN_ERR_ARG;
+    const long long es = dtype == PBN_F32 ? 4 : 2;
+    if (n_x_rows * (long long)ld_x * es >= (1LL << 32) || n_g_rows * (long long)ld_g * es >= (1LL << 32)) return PBN_ERR_RANGE;
+    if ((long long)n_pairs_total >= (1LL << 30)) return PBN_ERR_RANGE;
+    if (seg_begin && !pair_counts && !lists_padded) return PBN_ERR_ARG;
+    if (!in_idx && n_pairs_total > (n_x_rows < n_g_rows ? n_x_rows : n_g_rows)) return PBN_ERR_ARG;   // identity pairs: one per row
+    return pbn_spconv_wgrad(x, ld_x, g, ld_g, dtype, in_idx, out_idx, seg_begin, pair_counts, segment, n_pairs_total, n_offsets, cin,
+                            cout, dw, workspace, workspace_bytes, stream);
+}

@@ -112,3 +112,32 @@ def test_wgrad_ring_matches_round2_kernel():
     for ci, (o, (n, _, ref)) in enumerate(zip(old, new)):
         scale = max(1.0, ref.abs().max().item())
         assert (o - n).abs().max().item() <= 1e-4 * scale, "case %d" % ci
+
+
+def test_wgrad_checked_refuses_what_the_kernels_cannot_address():
+    """pbn_spconv_wgrad_checked (round 4; the entry the package calls): slabs of 4 GiB, 2^30 pairs -> PBN_ERR_RANGE; device-built
+    lists without their pair counts, more identity pairs than rows -> PBN_ERR_ARG.  Refused before any launch (the pointers are
+    never touched) -- and the same call with honest sizes runs."""
+    import ctypes
+    from pbnet_amd import _native as N
+    lib = N.lib()
+    x = torch.randn(64, 32, device=DEV).to(torch.bfloat16)
+    g = torch.randn(64, 16, device=DEV).to(torch.bfloat16)
+    dw = torch.empty(1, 32, 16, dtype=torch.float32, device=DEV)
+    ws = torch.empty(int(lib.pbn_spconv_wgrad_workspace_bytes(1, 32, 16)), dtype=torch.uint8, device=DEV)
+    idx = torch.arange(64, dtype=torch.int32, device=DEV)
+    seg = torch.tensor([0, 1], dtype=torch.int32, device=DEV)
+
+    def call(n_x, n_g, in_idx=None, out_idx=None, seg_begin=None, counts=None, padded=0, n_pairs=64):
+        return lib.pbn_spconv_wgrad_checked(N.c_vp(x.data_ptr()), 32, n_x, N.c_vp(g.data_ptr()), 16, n_g, 1, N.ptr(in_idx),
+                                            N.ptr(out_idx), N.ptr(seg_begin), N.ptr(counts), padded, 4096 if seg_begin is not None else 0,
+                                            n_pairs, 1, 32, 16, N.ptr(dw), N.c_vp(ws.data_ptr()), ws.numel(), N.current_stream())
+    assert call((1 << 32) // 64, 64) == N.PBN_ERR_RANGE                 # x slab: rows * 32 * 2 bytes = 4 GiB
+    assert call(64, (1 << 32) // 32) == N.PBN_ERR_RANGE                 # g slab
+    assert call(64, 64, n_pairs=1 << 30) == N.PBN_ERR_RANGE
+    assert call(64, 64, idx, idx, seg, None, 0) == N.PBN_ERR_ARG        # unpadded lists without their counts
+    assert call(32, 64, n_pairs=64) == N.PBN_ERR_ARG                    # identity pairs beyond the rows
+    assert call(64, 64) == 0
+    torch.cuda.synchronize()
+    want = x.float().t() @ g.float()
+    assert (dw[0] - want).abs().max().item() <= 1e-3
