@@ -564,7 +564,10 @@ int pick_cfg(const ConvArgs& a) {
     // round 4: their K-split over the tile's POPULATED steps (KLIST, 2202): 146 k-row probe 40->32 170 -> 154 us; level on 32->32
     // (94 / 95) and a loss on the 16-byte-row stem above, where a step spans four offsets and nearly every step is populated
     // (41 -> 65 us: the list costs more than the few steps it drops) -- so only rows of 4+ vectors take it
-    static const int klist = getenv("PBN_WAVE_KLIST") ? atoi(getenv("PBN_WAVE_KLIST")) : 1;
+    // In the pipeline: the 14A stem (34 -> 32 channels) 78.8 -> 66.7 us with one scene alone, and four scenes in flight measured
+    // 310 / 313 scenes/s with it against 318 / 328 without (run-to-run spread +-5 %): 12 us of 5 400 alone, nothing shown in
+    // flight -- OFF by default (PBN_WAVE_KLIST=1), kept with its tests (cfg 2201 / 2202).
+    static const int klist = getenv("PBN_WAVE_KLIST") ? atoi(getenv("PBN_WAVE_KLIST")) : 0;
     if (a.vpo <= 8 && a.K >= 64 && ntt % 2 == 0) return (klist && a.vpo >= 8) ? 2202 : 1202;
     int best = 0;
     long long best_wgs = -1;
