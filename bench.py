@@ -734,7 +734,8 @@ def main():
                                       "one scene per rank)", "ms_per_step": round(e / 12 * 1e3, 2),
                                       "allreduce_tail_ms_per_step": round(comm * 1e3, 2), "loss": round(loss, 5),
                                       "points_per_scene": it["n_points"], "voxels_per_scene": it["n_voxels"],
-                                      "phases_ms_synchronised": {k_: round(v_, 2) for k_, v_ in ph.items()}}
+                                      "phases_ms_synchronised": {k_: round(v_, 2) for k_, v_ in ph.items()},
+                                      "roofline": it.get("roofline")}
                 phase("train_step_leg")
             if world == 1 and not args.no_cpu_baseline:
                 cpu = cpu_baseline(cfg, model, raw)

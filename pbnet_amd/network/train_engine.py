@@ -32,6 +32,8 @@ ENABLED = os.environ.get("PBN_TRAIN_ENGINE", "1") == "1"     # "0": the module p
 # the step time is the same within noise (33.96 vs 34.36 ms), and in the caller's row order the arithmetic is, sum for sum,
 # the module path's -- which is what the exactness tests pin.
 SORTED = os.environ.get("PBN_TRAIN_SORTED", "0") == "1"
+# a list while a caller collects what one step's bodies compute (scripts/train_step.py: the step's roofline figure); None otherwise
+ACCOUNTING = None
 _DOWN = ("conv1p1s2", "conv2p2s2", "conv3p4s2", "conv4p8s2")
 _DOWN_BN = ("bn1", "bn2", "bn3", "bn4")
 _UP = ("convtr4p16s2", "convtr5p8s2", "convtr6p4s2", "convtr7p2s2")
@@ -317,6 +319,8 @@ class _BodyFn(torch.autograd.Function):
                                            padded.stride(0), tables[0], tables[1], tables[2], tables[3], vp(arena.data_ptr()),
                                            nbytes, vp(stats.data_ptr()), C._DT[dt], vp(ws.data_ptr()), ws.numel(),
                                            vp(bws.data_ptr()), bws.numel(), N.current_stream()), "pbn_unet_train_forward")
+        if ACCOUNTING is not None:
+            ACCOUNTING.append((plan, pyr, es))
         st = _State()
         st.plan, st.pyr, st.padded, st.arena, st.stats, st.offs, st.nbytes, st.n_rows, st.tables = \
             plan, pyr, padded, arena, stats, offs, nbytes, n_rows, tables
@@ -399,3 +403,50 @@ def forward_body(net, x):
     plan = _plan(net, feats.dtype, bool(feats.requires_grad))
     out = _BodyFn.apply(feats, net, pyr, perm, inv_perm, *plan.params)
     return SparseTensor(out, coordinate_manager=cm, tensor_stride=1)
+
+
+def step_accounting(records):
+    """Algorithmic flops and bytes of the bodies recorded in ACCOUNTING (one entry per network and forward): per op the forward
+    convolution, its input gradient (where the plan computes one) and its weight gradient -- 2 x pairs x C_in x C_out each, bytes as
+    SURVEY 8d counts them (input rows + output rows + kernel + 8 bytes per rule pair; the weight gradient writes its kernel in
+    fp32) -- and the batch norm's passes over the op's output slab (forward: statistics, apply [+ residual]; backward: two passes
+    over x, dy, y and the write of dx [+ the residual gradient]).  Reads the pair counts back: call it outside the timed region."""
+    flops = {"forward": 0, "dgrad": 0, "wgrad": 0}
+    nbytes = {"forward": 0, "dgrad": 0, "wgrad": 0, "batch_norm": 0}
+    n_ops = 0
+    for plan, pyr, es in records:
+        rows = list(pyr.n)
+        pair_cache = {}
+        for i, (conv, norm, mk, lin, lout, src, pre, res, out, relu) in enumerate(plan.recs):
+            cin, cout = int(conv.kernel.shape[-2]), int(conv.kernel.shape[-1])
+            k = _K_OF[mk]
+            v_in, v_out = rows[lin], rows[lout]
+            if mk == 0:
+                pairs = v_out
+            else:
+                slot = _pair_slot(mk, lin, lout)
+                if slot not in pair_cache:
+                    if slot < 5:
+                        nbr = pyr.kernel_map(1 << slot, 3)
+                    elif slot == 5:
+                        nbr = pyr.kernel_map(1, 5)
+                    elif slot < 10:
+                        nbr = pyr.down_map(1 << (slot - 6))
+                    else:
+                        nbr = pyr.up_map(2 << (slot - 10))
+                    pair_cache[slot] = int(C.rulebook_pairs_dev(nbr)[3].sum().item())
+                pairs = pair_cache[slot]
+            f = 2 * pairs * cin * cout
+            io = (v_in * cin + v_out * cout) * es
+            maps = 8 * pairs if mk else 0
+            flops["forward"] += f
+            nbytes["forward"] += io + k * cin * cout * es + maps
+            if plan.ops[i].want_dx:
+                flops["dgrad"] += f
+                nbytes["dgrad"] += io + k * cin * cout * es + maps
+            flops["wgrad"] += f
+            nbytes["wgrad"] += io + maps + k * cin * cout * 4
+            slab = v_out * cout * es
+            nbytes["batch_norm"] += (3 + (1 if res is not None else 0)) * slab + (7 + (1 if res is not None else 0)) * slab
+            n_ops += 1
+    return {"ops": n_ops, "flops": flops, "bytes": nbytes, "flops_total": sum(flops.values()), "bytes_total": sum(nbytes.values())}

@@ -117,9 +117,31 @@ def run_training(world, rank, dev, dist, steps=5, warmup=2, dtype=None, comm_dty
         for _ in range(5):
             step_phases()
         phases_out.update({k: v / 5 * 1e3 for k, v in phases.items()})
+    # the step's roofline figure: what the three bodies compute in one step (forward, input and weight gradients of every
+    # convolution, the batch norms' passes) over the measured step time -- the WHOLE step (coordinates, grouping, glue, losses, Adam
+    # included in the time, not in the work): a lower bound of what the kernels reach
+    roof = None
+    if torch.cuda.is_available() and not small:
+        from pbnet_amd.network import train_engine as TE
+        TE.ACCOUNTING = []
+        step()
+        torch.cuda.synchronize()
+        recs, TE.ACCOUNTING = TE.ACCOUNTING, None
+        if recs:
+            acc = TE.step_accounting(recs)
+            t_step = elapsed / max(steps, 1)
+            roof = {"work": "forward + input gradient + weight gradient of the %d convolutions of the three U-Net bodies (2 x pairs x "
+                            "C_in x C_out each) and their batch norms; bytes as SURVEY 8d" % acc["ops"],
+                    "flops_per_step": acc["flops_total"], "bytes_per_step": acc["bytes_total"],
+                    "flops_by_pass": acc["flops"], "bytes_by_pass": acc["bytes"],
+                    "achieved_tflops": round(acc["flops_total"] / t_step / 1e12, 2), "mfma_peak_tflops": 2500.0,
+                    "frac_mfma": round(acc["flops_total"] / t_step / 2.5e15, 4),
+                    "achieved_GBps": round(acc["bytes_total"] / t_step / 1e9, 1), "hbm_peak_GBps": 8000.0,
+                    "frac_hbm": round(acc["bytes_total"] / t_step / 8e12, 4), "bound": "hbm",
+                    "note": "over the whole step time (coordinates, grouping, glue, losses and Adam are in the time, not in the work)"}
     if dist is not None and dist.is_initialized():
         pd.sync_buffers(model)                                      # what precedes validation / checkpoint_save
-    info = dict(info, reducer=reducer.wire_stats())
+    info = dict(info, reducer=reducer.wire_stats(), roofline=roof)
     return elapsed, t_comm[0] / max(comm_steps, 1), float(loss.detach()), info
 
 
@@ -221,7 +243,8 @@ def main():
                           "points_per_scene": info["n_points"], "voxels_per_scene": info["n_voxels"],
                           "gradient_buckets": info["reducer"]["buckets"], "bytes_on_the_wire_per_rank_per_step": info["reducer"]["bytes_per_step"],
                           "largest_bucket_bytes": info["reducer"]["largest_bucket_bytes"],
-                          "used_flags_over_host_group": info["reducer"]["host_group_for_used_flags"]}), flush=True)
+                          "used_flags_over_host_group": info["reducer"]["host_group_for_used_flags"],
+                          "roofline": info.get("roofline")}), flush=True)
 
 
 if __name__ == "__main__":
