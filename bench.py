@@ -505,6 +505,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the stage breakdown, the TTA leg and the CPU baseline")
+    ap.add_argument("--switch-interval", type=float, default=float(os.environ.get("PBN_BENCH_SWITCH", "0") or 0),
+                    help="sys.setswitchinterval for the in-flight host threads (0 = Python's default 5 ms)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="scenes in flight per GPU (one host thread + HIP stream each); 1 = the reference's loop")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
@@ -546,6 +548,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.switch_interval > 0:
+        sys.setswitchinterval(args.switch_interval)
     runner = Runner(model, b, t, args.inflight, device)
     one_step(model, b, t)                   # fills the weight / threshold caches once, on one thread
     torch.cuda.synchronize()
