@@ -188,6 +188,32 @@ def test_pbnet_training_step_runs():
     for prefix in ("D_Unet.", "score_Unet.", "linear_binary.", "linear_IOU.", "MEUnet."):
         assert any(g.startswith(prefix) for g in got), prefix
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    # round 4: the index-only glue between the networks on the fused launches (PBNet.TRAIN_FUSED_GLUE, the default) against the
+    # plain-torch glue on the same weights and batch: the same integers (proposals), the same loss, the same gradients
+    import pbnet_amd.network.PBNet as PB
+    assert PB.TRAIN_FUSED_GLUE
+    fused = (loss.detach().clone(), [x.clone() for x in pred["proposals"][:3]], pred["clt_scores"].detach().clone(),
+             {n_: p.grad.detach().clone() for n_, p in model.named_parameters() if p.grad is not None})
+    try:
+        PB.TRAIN_FUSED_GLUE = False
+        for p in model.parameters():
+            p.grad = None
+        batch2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        loss2, pred2, _, _ = model_fn(batch2, model, 1, cfg, "train")
+        loss2.backward()
+    finally:
+        PB.TRAIN_FUSED_GLUE = True
+    for a, b in zip(fused[1], pred2["proposals"][:3]):
+        assert torch.equal(a.cpu(), b.cpu())
+    # train-mode batch norm updated its running statistics between the two forwards: statistics of the batch, not the running ones,
+    # normalise in training, so the outputs are the same numbers
+    assert torch.equal(fused[2], pred2["clt_scores"].detach())
+    assert abs(float(fused[0]) - float(loss2.detach())) <= 1e-6 * max(1.0, abs(float(loss2.detach())))
+    grads2 = {n_: p.grad for n_, p in model.named_parameters() if p.grad is not None}
+    assert set(grads2) == set(fused[3])
+    for n_, g in grads2.items():
+        d = (g.float() - fused[3][n_].float()).abs().max().item()
+        assert d <= 1e-5 * max(1.0, g.float().abs().max().item()), (n_, d)
 
 
 def test_rulebook_pairs_against_nonzero():
