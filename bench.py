@@ -57,7 +57,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_SUMMARIES = ("r04_c_pmc_summary.json", "r04_b_pmc_summary.json", "r04_a_pmc_summary.json", "r03_c_pmc_summary.json", "r03_b_pmc_summary.json", "r03_a_pmc_summary.json", "r02_b_pmc_summary.json", "r02_a_pmc_summary.json", "r01_pmc_summary.json")   # newest first
+PMC_SUMMARIES = ("r04_d_pmc_summary.json", "r04_c_pmc_summary.json", "r04_b_pmc_summary.json", "r04_a_pmc_summary.json", "r03_c_pmc_summary.json", "r03_b_pmc_summary.json", "r03_a_pmc_summary.json", "r02_b_pmc_summary.json", "r02_a_pmc_summary.json", "r01_pmc_summary.json")   # newest first
 
 
 WORKLOADS = {
