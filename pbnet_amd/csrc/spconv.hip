@@ -619,7 +619,13 @@ static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const i
     a.dbg = dbg_env;
     // coarse levels (and whatever PBN_CONV_FAMILY selects): the wave-autonomous family of spconv_wave.hip -- K split over
     // the waves of a workgroup instead of over workgroups: no fp32 partial slabs, no second launch
+    if (rows_per_wave >= 10000) return launch_rs(a, dtype, rows_per_wave - 10000, stream);   // explicit row-stationary configuration
     if (rows_per_wave >= 100) return launch_wave(a, dtype, rows_per_wave, stream);   // explicit configuration (tests, tuning)
+    // wide levels (round 5): one tile per CU, weights streamed once per CU (spconv_rs.hip)
+    if (rows_per_wave == 0 && rs_family_wanted(a, dtype)) {
+        const int rc = launch_rs(a, dtype, 0, stream);
+        if (rc != PBN_ERR_UNSUPPORTED) return rc;
+    }
     if (rows_per_wave == 0 && wave_family_wanted(a, dtype)) {
         static const int force_cfg = getenv("PBN_WAVE_CFG") ? atoi(getenv("PBN_WAVE_CFG")) : 0;
         const int rc = launch_wave(a, dtype, force_cfg, stream);

@@ -169,6 +169,10 @@ bool wave_family_wanted(const ConvArgs& a, int dtype);
 // spconv_wave.hip: channel tiles per workgroup / groups / block order of the launch `a` will become (automatic configuration)
 void describe_launch(const ConvArgs& a, int dtype, LaunchDesc* d);
 
+// spconv_rs.hip (round 5): row-stationary big-tile family for the wide levels.  cfg 0 = automatic tile height, 1..5 = fragments per wave
+bool rs_family_wanted(const ConvArgs& a, int dtype);
+int launch_rs(const ConvArgs& a, int dtype, int cfg, hipStream_t stream);
+
 // spconv_halo.hip: LDS-staged family over halo tables (pbn_halo_build); PBN_ERR_UNSUPPORTED when the shape is not built
 bool halo_supported(const ConvArgs& a, int tile_rows);
 int launch_halo(const ConvArgs& a, int dtype, const int* cnt, const int* rows, const unsigned short* loc,
