@@ -118,6 +118,10 @@ SIGNATURES = {
                                    c_f32p, c_f32p, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "pbn_spconv_forward_dual": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_int, c_vp, c_int, c_int, c_int, c_f32p, c_f32p,
                                         c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp, c_int, c_int, c_int, c_vp]),
+    "pbn_rs_table_bytes": (c_size, [c_int, c_int]),
+    "pbn_rs_table_build": (c_int, [c_i32p, c_int, c_i32p, c_int, c_vp, c_size, c_vp]),
+    "pbn_spconv_forward_tab": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_int, c_vp, c_int, c_int, c_int, c_f32p, c_f32p,
+                                       c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp, c_vp]),
     "pbn_halo_bytes": (c_size, [c_int, c_int, c_int, ctypes.POINTER(HaloLayout)]),
     "pbn_halo_build": (c_int, [ctypes.POINTER(HaloJob), c_int, c_vp]),
     "pbn_spconv_forward_halo": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_int, c_vp, c_int, c_int, c_int, c_f32p,

@@ -611,6 +611,7 @@ static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const i
     // with the other scenes' working sets for the same L2s and every op reads 1.1 MB more.  Off by default.
     static const int pf_env = getenv("PBN_CONV_PREFETCH") ? atoi(getenv("PBN_CONV_PREFETCH")) : 0;   // 0 off, 1 with ownership, 2 plain slices
     a.pf_w = nullptr; a.pf_steps = a.pf_ntt = a.pf_nt = a.pf_groups = 0;
+    a.rs_table = (nbr && g_rs_table.nbr == nbr && g_rs_table.n_out == n_out && n_in == n_out) ? g_rs_table.table : nullptr;
     if (pf_env && g_next_weights.w) {
         a.pf_w = g_next_weights.w; a.pf_steps = g_next_weights.steps; a.pf_ntt = g_next_weights.ntt;
         a.pf_nt = g_next_weights.nt; a.pf_groups = pf_env == 1 ? g_next_weights.groups : 0;
@@ -642,7 +643,10 @@ static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const i
     }
 }
 
-namespace pbn { thread_local NextWeights g_next_weights = {nullptr, 0, 0, 0, 0}; }
+namespace pbn {
+thread_local NextWeights g_next_weights = {nullptr, 0, 0, 0, 0};
+thread_local RsTableRef g_rs_table = {nullptr, nullptr, 0};
+}
 
 extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
                                   const int32_t* row_perm, const int32_t* n_out_dev, int n_out, const void* w_packed,
@@ -653,6 +657,20 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, cons
     return spconv_forward_impl(in_feat, ld_in, n_in, nbr, n_offsets, row_perm, n_out_dev, n_out, w_packed, vecs_per_offset,
                                n_steps, cout_padded, scale, shift, residual, ld_res, relu, out_feat, ld_out, dtype,
                                rows_per_wave, workspace, workspace_bytes, stream_, nullptr, 0, 0, 0);
+}
+
+// pbn_spconv_forward with the map's row-stationary tables (pbn_rs_table_build; null = none)
+extern "C" int pbn_spconv_forward_tab(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
+                                      const int32_t* n_out_dev, int n_out, const void* w_packed, int vecs_per_offset, int n_steps,
+                                      int cout_padded, const float* scale, const float* shift, const void* residual, int ld_res,
+                                      int relu, void* out_feat, int ld_out, int dtype, int rows_per_wave, void* workspace,
+                                      size_t workspace_bytes, const void* rs_table, pbn_stream_t stream_) {
+    g_rs_table = RsTableRef{nbr, rs_table, n_out};
+    const int rc = spconv_forward_impl(in_feat, ld_in, n_in, nbr, n_offsets, nullptr, n_out_dev, n_out, w_packed, vecs_per_offset,
+                                       n_steps, cout_padded, scale, shift, residual, ld_res, relu, out_feat, ld_out, dtype,
+                                       rows_per_wave, workspace, workspace_bytes, stream_, nullptr, 0, 0, 0);
+    g_rs_table = RsTableRef{nullptr, nullptr, 0};
+    return rc;
 }
 
 extern "C" int pbn_spconv_forward_dual(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
