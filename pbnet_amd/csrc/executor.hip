@@ -220,6 +220,13 @@ extern "C" size_t pbn_unet_arena_bytes(const pbn_unet_buf* bufs, int n_bufs, con
 
 static thread_local const pbn_unet_halo* g_unet_halo = nullptr;
 extern "C" void pbn_unet_set_halo(const pbn_unet_halo* halo) { g_unet_halo = halo; }
+// the tables armed for this thread's next forward: taken (and disarmed) at the top of EVERY entry point, before any early return,
+// so that a failed call never leaves a pointer to a caller-owned struct behind for the next lineage
+static const pbn_unet_halo* take_halo() {
+    const pbn_unet_halo* h = g_unet_halo;
+    g_unet_halo = nullptr;
+    return h;
+}
 
 // Where the staged-row kernels pay (round 4, scripts/probe_halo.py with four streams on the bench scene's levels): K-split over
 // 64-row tiles on levels of 4 k - 20 k rows for every wide k = 3 layer up to 256 input channels (x1.2-1.5 in flight), on levels
@@ -241,9 +248,7 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
                              const int32_t* n_rows, const void* input, int ld_input, const int32_t* const* k3,
                              const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
                              size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream,
-                             hipEvent_t* events, const int32_t* n_rows_dev = nullptr) {
-    const pbn_unet_halo* halo = g_unet_halo;
-    g_unet_halo = nullptr;
+                             hipEvent_t* events, const pbn_unet_halo* halo, const int32_t* n_rows_dev = nullptr) {
     if (!ops || !bufs || !n_rows || !input || !arena || n_ops < 1 || n_bufs < 2 || n_bufs > 512) return PBN_ERR_ARG;
     int64_t offs[512];
     if (pbn_unet_arena_bytes(bufs, n_bufs, n_rows, dtype, offs) > arena_bytes) return PBN_ERR_WORKSPACE;
@@ -251,8 +256,9 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
     char* A = (char*)arena;
     // Round 5: tables of the staged row-stationary kernels (spconv_rs.hip) for the k = 3 maps of the levels where they pay, built
     // by the first op of this call that uses them, at the END of the split-K workspace (the ops see the rest); an op over that
-    // map runs with g_rs_table set.  PBN_UNET_RS_TABLES=0: none (the kernels then build a tile's tables in their prologue).
-    static const int rs_tab_env = getenv("PBN_UNET_RS_TABLES") ? atoi(getenv("PBN_UNET_RS_TABLES")) : 1;
+    // map runs with g_rs_table set.  OFF by default (PBN_UNET_RS_TABLES=1 switches it on): measured inside the pipeline the build
+    // (~20-25 us per map and forward) costs what the layers of the level give back (spconv_rs.hip: "Where each form pays").
+    static const int rs_tab_env = getenv("PBN_UNET_RS_TABLES") ? atoi(getenv("PBN_UNET_RS_TABLES")) : 0;
     void* rs_tab[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool rs_tab_built[5] = {false, false, false, false, false};
     if (rs_tab_env && dtype != PBN_F32 && splitk_ws && k3) {
@@ -297,7 +303,8 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
         const void* res = o.res_buf >= 0 ? base(o.res_buf) + (size_t)o.res_col * es : nullptr;
         // the NEXT op's packed weights are touched by this op's workgroups (spconv_common.h: prefetch_next_weights)
         g_next_weights = NextWeights{nullptr, 0, 0, 0, 0};
-        if (i + 1 < n_ops) {
+        static const int pf_env = getenv("PBN_CONV_PREFETCH") ? atoi(getenv("PBN_CONV_PREFETCH")) : 0;   // (off by default: nothing to describe)
+        if (pf_env && i + 1 < n_ops) {
             const pbn_unet_op& q = ops[i + 1];
             if (q.in_buf >= 0 && q.in_buf < n_bufs && q.level_in >= 0 && q.level_in <= 4 && q.level_out >= 0 && q.level_out <= 4 && q.w) {
                 ConvArgs nx;
@@ -358,7 +365,7 @@ extern "C" int pbn_unet_forward(const pbn_unet_op* ops, int n_ops, const pbn_une
                                 const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
                                 size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream) {
     return unet_forward_impl(ops, n_ops, bufs, n_bufs, n_rows, input, ld_input, k3, k5, down, up, arena, arena_bytes, dtype,
-                             splitk_ws, splitk_bytes, stream, nullptr);
+                             splitk_ws, splitk_bytes, stream, nullptr, take_halo());
 }
 
 // capacity form: n_rows are capacities, the rows that exist are n_rows_dev[level] (device); launches are sized by the
@@ -368,9 +375,10 @@ extern "C" int pbn_unet_forward_dev(const pbn_unet_op* ops, int n_ops, const pbn
                                     const int32_t* const* k3, const int32_t* k5, const int32_t* const* down,
                                     const int32_t* const* up, void* arena, size_t arena_bytes, int dtype, void* splitk_ws,
                                     size_t splitk_bytes, pbn_stream_t stream) {
+    const pbn_unet_halo* halo = take_halo();          // consumed by THIS call whatever it returns
     if (!n_rows_dev) return PBN_ERR_ARG;
     return unet_forward_impl(ops, n_ops, bufs, n_bufs, n_rows_cap, input, ld_input, k3, k5, down, up, arena, arena_bytes, dtype,
-                             splitk_ws, splitk_bytes, stream, nullptr, n_rows_dev);
+                             splitk_ws, splitk_bytes, stream, nullptr, halo, n_rows_dev);
 }
 
 // Measurement variant: brackets every op with HIP events on the launching stream, SYNCHRONISES the stream at the end and
@@ -380,6 +388,7 @@ extern "C" int pbn_unet_forward_timed(const pbn_unet_op* ops, int n_ops, const p
                                       const int32_t* k5, const int32_t* const* down, const int32_t* const* up,
                                       void* arena, size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes,
                                       pbn_stream_t stream, float* op_ms) {
+    const pbn_unet_halo* halo = take_halo();          // consumed by THIS call whatever it returns
     if (!op_ms || n_ops < 1 || n_ops > 4096) return PBN_ERR_ARG;
     hipEvent_t* ev = new hipEvent_t[2 * (size_t)n_ops];
     int made = 0, rc = PBN_OK;
@@ -387,7 +396,7 @@ extern "C" int pbn_unet_forward_timed(const pbn_unet_op* ops, int n_ops, const p
         if (hipEventCreate(&ev[made]) != hipSuccess) { rc = PBN_ERR_HIP; break; }
     if (rc == PBN_OK)
         rc = unet_forward_impl(ops, n_ops, bufs, n_bufs, n_rows, input, ld_input, k3, k5, down, up, arena, arena_bytes,
-                               dtype, splitk_ws, splitk_bytes, stream, ev);
+                               dtype, splitk_ws, splitk_bytes, stream, ev, halo);
     if (rc == PBN_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = PBN_ERR_HIP;
     if (rc == PBN_OK)
         for (int i = 0; i < n_ops; ++i)

@@ -634,6 +634,10 @@ extern "C" int pbn_spconv_forward_halo(const void* in_feat, int ld_in, int n_in,
         cout_padded < 16 || (cout_padded & 15) || !halo_table || !halo || !nbr)
         return PBN_ERR_ARG;
     if (n_steps != n_offsets * (vecs_per_offset >> 2) || halo->n_offsets != n_offsets) return PBN_ERR_ARG;
+    {   // the table must have been laid out for THIS map: a table of another lineage or capacity would be indexed out of bounds
+        pbn_halo_layout chk;
+        if (!pbn_halo_bytes(n_out, n_offsets, halo->tile_rows, &chk) || memcmp(&chk, halo, sizeof(chk)) != 0) return PBN_ERR_ARG;
+    }
     if (n_out == 0) return PBN_OK;
     if (!in_feat || !w_packed || !out_feat) return PBN_ERR_ARG;
     const int esz = dtype == PBN_F32 ? 4 : 2;

@@ -1115,13 +1115,19 @@ int rs_cg(const ConvArgs& a) {
 
 }  // namespace
 
-// Where each form pays (MI355X, bench scene, HIP-graph replay, bf16; scripts/probe_rs.py, gpurun_out/r05_probe_rs_10.txt):
-//   k = 3 cube maps with the map's tables: the staged form wins on levels of >= ~100 k rows with 96 output channels (96->96 at
-//   146 k rows 96.5 -> 74.6 us, 128->96 135.8 -> 91.6) and on >= ~40 k rows with 32 output channels (57 k rows 21.4 -> 16.2);
-//   on 57 k rows x 96 channels it only draws (tiles of 240 rows: the weights are streamed per 240 rows again);
-//   every other wide launch (no table, strided / transposed maps, mid-size levels): the gather form, a few per cent to 17 % ahead
-//   of k_spconv (k = 2 transposed 96->96 at 146 k rows 49.0 -> 40.8 us) -- except the one shape whose registers spill (128 input
-//   channels at 5 fragments per wave), which takes the staged form with in-kernel tables (135.8 -> 109.6).
+// Where each form pays (MI355X, bench scene, bf16).  Single layers from a HIP graph (scripts/probe_rs.py, gpurun_out/r05_probe_rs_10.txt):
+// k = 3 cube maps with the map's tables, staged form: 96->96 at 146 k rows 96.5 -> 74.6 us (gather form 82.1), 128->96 135.8 -> 91.6,
+// 32->32 at 57 k rows 21.4 -> 16.2; 96 channels at 57 k rows only draws (tiles of 240 rows: the weights are streamed per 240 rows again).
+// Inside the pipeline (scripts/op_table.py, gpurun_out/r05_op_table_*.txt; scripts/ab_rs.sh: alternating bench runs on one box) the
+// tables do not earn their build: the first layer of a level pays ~20-25 us for them, the three to five layers that follow give
+// back 5-8 us each -- convolution ops of one scene 3 490 us (k_spconv) -> 3 332 (tables) / 3 340 (none), and with four scenes in
+// flight 330-332 scenes/s (k_spconv) -> 325-335 (tables) / 341-342 (none).  So by default no tables are built
+// (PBN_UNET_RS_TABLES=1 builds them), and the automatic choice is:
+//   * the gather form for every wide launch it is built for (a few per cent to 20 % ahead of k_spconv: 96->96 at 146 k rows
+//     93.7-98.8 -> 79.9-86.3 us, k = 2 transposed 96->96 47.1 -> 40.7, 128->96 at 26 k rows 46.0 -> 35.6), from 20 k rows for 96 output
+//     channels and from 40 k rows for 32 (at 26 k rows x 32 channels it loses: 12.4 -> 18.8);
+//   * the staged form with in-kernel tables for the one shape whose gather instantiation spills (128 input channels at 5
+//     fragments per wave: 128->96 at 146 k rows 163 -> 118.5 us), and for cube maps that come with tables.
 bool rs_staged_pays(int n_out, int ntiles_total) {
     static const int min6 = getenv("PBN_RSH_MIN_ROWS6") ? atoi(getenv("PBN_RSH_MIN_ROWS6")) : 100000;
     static const int min2 = getenv("PBN_RSH_MIN_ROWS2") ? atoi(getenv("PBN_RSH_MIN_ROWS2")) : 40000;
@@ -1131,11 +1137,12 @@ bool rs_staged_pays(int n_out, int ntiles_total) {
 bool rs_family_wanted(const ConvArgs& a, int dtype) {
     static const int env = getenv("PBN_CONV_RS") ? atoi(getenv("PBN_CONV_RS")) : 1;
     static const int min_rows = getenv("PBN_RS_MIN_ROWS") ? atoi(getenv("PBN_RS_MIN_ROWS")) : 20000;
+    static const int min_rows2 = getenv("PBN_RS_MIN_ROWS2") ? atoi(getenv("PBN_RS_MIN_ROWS2")) : 40000;
     if (!env || dtype == PBN_F32 || a.row_perm || a.K > 32 || a.n_out < min_rows) return false;
     const int cg = rs_cg(a);
     if (!cg) return false;
     const int nt = a.ntiles_total;
-    return (nt == 6 && (cg == 3 || cg == 4)) || (nt == 2 && cg == 1);
+    return (nt == 6 && (cg == 3 || cg == 4)) || (nt == 2 && cg == 1 && a.n_out >= min_rows2);
 }
 
 // cfg: 0 = automatic (form and tile height); 1..5 = that many fragments per wave (tests, tuning); + 1000: the staged form (rows in

@@ -55,6 +55,25 @@ class MinkUNet(nn.Module):
     # round 4: a BasicBlock's 1x1 shortcut (Mink.py:77-87) runs as extra reduction steps of the block's second convolution
     # (pbn_spconv_forward_dual): 7 launches fewer per network and no residual slab.  PBNET_FOLD_SHORTCUT=0: separate launches.
     FOLD_SHORTCUT = os.environ.get("PBNET_FOLD_SHORTCUT", "1") != "0"
+
+    def _fold_is_safe(self, blk, dtype):
+        """The folded form multiplies the BatchNorm scales gamma / sqrt(var + eps) into the 16-bit weights (the separate launches
+        apply them in the fp32 epilogue).  In fp16 a very small running variance can push |w * scale| past 65504 and a very large
+        one can push the bulk of the products into the subnormals: fold only when the scaled weights stay inside fp16's normal
+        range (largest magnitude below 3e4, and at most 1 % of the non-zero products below 6.1e-5); bf16 and fp32 have fp32's
+        exponent range.  (ADVICE round 4; tests/test_backbone_gpu.py::test_fold_guard_extreme_batchnorm_statistics)"""
+        if dtype != torch.float16:
+            return True
+        for conv, bn in ((blk.conv2, blk.norm2), (blk.downsample[0], blk.downsample[1])):
+            cout = int(conv.kernel.shape[-1])
+            s, _ = self._fold(bn, (cout + 15) // 16 * 16)
+            w = (conv.kernel.detach().float() * s[:cout]).abs()
+            nz = w[w > 0]
+            if nz.numel() == 0:
+                continue
+            if float(nz.max()) > 3.0e4 or float((nz < 6.1e-5).float().mean()) > 0.01:
+                return False
+        return True
     MORTON = os.environ.get("PBNET_MORTON", "1") != "0"   # fused path runs the lineage in Z-order (L2-local gathers)
     OP_TIMING_SINK = None   # callable(model, plan, rows, cm, esz, op_ms) installed by bench.py's roofline probe
 
@@ -245,7 +264,8 @@ class MinkUNet(nn.Module):
                 last_out = out if bi == len(blocks) - 1 else None
                 if blk.downsample is not None and self.FOLD_SHORTCUT:
                     from ..MinkowskiEngine.conv import _vpo
-                    if _vpo(int(blk.conv2.kernel.shape[-2]), dtype) % 4 == 0 and _vpo(int(blk.downsample[0].kernel.shape[-2]), dtype) % 4 == 0:
+                    if _vpo(int(blk.conv2.kernel.shape[-2]), dtype) % 4 == 0 and _vpo(int(blk.downsample[0].kernel.shape[-2]), dtype) % 4 == 0 \
+                            and self._fold_is_safe(blk, dtype):
                         cur = add_folded(blk, h, cur, l, last_out)
                         continue
                 res = cur

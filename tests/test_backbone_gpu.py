@@ -513,3 +513,34 @@ def test_folded_shortcuts_equal_separate_launches(arch):
     net._plans.clear()
     assert nops[False] - nops[True] == 7, nops
     _close(outs[True], outs[False], "%s folded vs separate shortcuts" % arch)
+
+
+def test_fold_guard_extreme_batchnorm_statistics():
+    """the folded shortcut multiplies BatchNorm scales into 16-bit weights.  With a running variance of 1e-12
+    (scale ~1e6) the products leave fp16's range: the planner must keep such a block on the separate launches (scales in the fp32
+    epilogue) -- the fp16 forward stays finite and equals the forward with folding switched off, bit for bit; bf16 keeps folding."""
+    from pbnet_amd.network.mink_unet import MinkUNet
+    coords = _scene_coords(53, room=(0.8, 0.6, 0.5), batch=1)
+    torch.manual_seed(7)
+    net = Mink_unet(in_channels=3, out_channels=20, arch="MinkUNet14A").to(DEV).eval()
+    blocks = [b for m in net.modules() if hasattr(m, "downsample") and m.downsample is not None for b in [m]]
+    assert blocks
+    with torch.no_grad():
+        for i, blk in enumerate(blocks):
+            (blk.norm2 if i % 2 == 0 else blk.downsample[1]).bn.running_var.fill_(1e-12 if i % 4 < 2 else 1e12)
+    for blk in blocks:
+        assert not net._fold_is_safe(blk, torch.float16)
+        assert net._fold_is_safe(blk, torch.bfloat16)
+    feats = torch.randn(len(coords), 3) * 1e-3
+    x = ME.SparseTensor(feats.to(torch.float16), torch.from_numpy(coords), device=DEV)
+    with torch.no_grad():
+        a = net(x).F.float()
+        old = MinkUNet.FOLD_SHORTCUT
+        try:
+            MinkUNet.FOLD_SHORTCUT = False
+            net._plans.clear()
+            b = net(x).F.float()
+        finally:
+            MinkUNet.FOLD_SHORTCUT = old
+            net._plans.clear()
+    assert torch.equal(a, b), "guarded blocks must run the separate launches"

@@ -52,3 +52,21 @@ def test_train_step_entry_two_ranks():
     assert line["dry_run"] is True and line["n_gpus"] == 2 and line["steps"] == 3
     assert line["replicas_identical"] is True            # the same averaged gradient reached both replicas every step
     assert line["unused_grads_none"] is True             # find_unused_parameters semantics: no state for untrained branches
+
+
+def test_bench_spawns_its_own_ranks_eight_ranks_four_threads():
+    """`python bench.py --gpus 8` (the N = 1 command with another N, no launcher, WORLD_SIZE unset) starts
+    its eight ranks itself -- children of a process that never touches the GPU -- and rank 0's ONE JSON line comes back; every rank
+    runs its steps on four host threads (the in-flight mode), i.e. 8 x 4 threads on this box's cores: the host-side shape of the
+    8-GPU run, with gloo and a stand-in step."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "16", "--warmup", "4",
+                          "--inflight", "4", "--dry-run"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["dry_run"] is True and line["n_gpus"] == 8 and line["steps"] == 16
+    assert line["config"]["scene_shard_sizes"] == [8] * 8 and line["config"]["host_threads_per_rank"] == 4
+
