@@ -206,49 +206,6 @@ int pbn_spconv_forward_tab(const void* in_feat, int ld_in, int n_in, const int32
 int pbn_gather_rows(const void* in, int ld_in_bytes, const int64_t* idx, int n, int row_bytes, void* out,
                     int ld_out_bytes, pbn_stream_t stream);
 
-/* ------------------------------------------------------------------------------------------------------------
- * LDS-staged ("halo") form of the same convolution (csrc/spconv_halo.hip; same reference call sites as
- * pbn_spconv_forward: network/Mink.py:293-350).  A kernel map is cut into tiles of `tile_rows` consecutive output rows; per
- * tile, ONCE per coordinate lineage, pbn_halo_build derives
- *   cnt    int32  [tiles]                    distinct input rows the tile names (-1: more than the list holds; the tile then
- *                                            runs a plain gather loop -- same results)
- *   rows   int32  [tiles][pitch]             those rows, ascending
- *   loc    uint16 [tiles][tile_rows][K]      nbr[o][k] as a slot of the tile's list, 0xffff = no neighbour
- *   fmask  uint16 [tiles][K]                 bit f: rows 16 f .. 16 f + 15 of the tile have a neighbour at offset k
- * and every layer that convolves over the map stages the tile's rows once in LDS instead of gathering them per offset.
- * Pays on Z-ordered lineages (pbn_coords_prepare), where a 128-row tile names 1.4-2.4x as many distinct rows as it has
- * rows; correct on any map.  Offsets in the layout are bytes from the table base (pbn_halo_bytes fills it). */
-typedef struct {
-    int64_t cnt, rows, loc, fmask;
-    int32_t tile_rows, n_offsets, pitch, tiles;
-} pbn_halo_layout;
-
-typedef struct {
-    const int32_t* nbr;         /* [n_out, n_offsets] */
-    const int32_t* n_out_dev;   /* optional device-side row count (n_out is then the capacity) */
-    void* table;                /* pbn_halo_bytes(n_out, ...) bytes */
-    pbn_halo_layout layout;
-    int32_t n_out;
-    int32_t max_rows;           /* 0 = default; smaller values mark tiles with more distinct rows (tests of the gather loop) */
-} pbn_halo_job;
-
-size_t pbn_halo_bytes(int n_out, int n_offsets, int tile_rows, pbn_halo_layout* layout);
-/* the tables of up to 16 maps in ONE launch */
-int pbn_halo_build(const pbn_halo_job* jobs, int n_jobs, pbn_stream_t stream);
-/* pbn_spconv_forward over a map with halo tables (tile_rows 32 / 64: K split over the waves of a workgroup, 128 / 256: a
- * wave per 32 / 64 rows; vecs_per_offset a multiple of 4; no row_perm).
- * lds_slots: rows of the LDS buffer (0 = default); a tile with more distinct rows runs once per segment of its list.
- * cfg: 0 = automatic; > 0: 10000 * depth + (1000 * ksplit + 100 * NF + NT), the configuration code of the wave-autonomous
- * family (pbn_spconv_forward, rows_per_wave >= 100) whose tile must match tile_rows, depth = weight stages in flight (0, 2,
- * 3); < 0: the barrier-synchronised experiment of csrc/spconv_halo.hip, -(100 * S + 10 * RING + CSP) with S 3..4, RING 2 -- explicit values
- * for tests and tuning.
- * PBN_ERR_UNSUPPORTED for shapes this family does not build (the caller falls back to pbn_spconv_forward). */
-int pbn_spconv_forward_halo(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
-                            const int32_t* n_out_dev, int n_out, const void* w_packed, int vecs_per_offset, int n_steps,
-                            int cout_padded, const float* scale, const float* shift, const void* residual, int ld_res,
-                            int relu, void* out_feat, int ld_out, int dtype, const void* halo_table,
-                            const pbn_halo_layout* halo, int lds_slots, int cfg, pbn_stream_t stream);
-
 /* Per-batch global max and/or average pooling of a slab whose rows are grouped by batch index
  * (MinkowskiGlobalMaxPooling / MinkowskiGlobalAvgPooling of the score branch, network/PBNet.py:67-68,274-276).
  * seg_start int32[n_seg+1] row offsets; out_max / out_avg f32 [n_seg, channels] (either may be NULL).
@@ -608,16 +565,7 @@ typedef struct {
     int32_t level, width;
 } pbn_unet_buf;
 
-/* Optional halo tables of the lineage's k = 3 maps (pbn_halo_build), one per level or NULL: where a table is given and the op's
- * shape is one the staged-row kernels win on (csrc/executor.hip: halo_wanted), the op runs on csrc/spconv_wave_halo.hip. */
-typedef struct {
-    const void* table[5];
-    pbn_halo_layout layout[5];
-} pbn_unet_halo;
-
 size_t pbn_unet_arena_bytes(const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows, int dtype, int64_t* buf_offsets);
-/* thread-local: the tables the NEXT pbn_unet_forward* call of this thread uses (NULL = none); cleared by that call */
-void pbn_unet_set_halo(const pbn_unet_halo* halo);
 int pbn_unet_forward_dev(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows_cap,
                          const int32_t* n_rows_dev, const void* input, int ld_input, const int32_t* const* k3,
                          const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,

@@ -292,55 +292,6 @@ def spconv_forward_dual(feats, nbr, n_out, feats2, packed, vpo2, shift=None, sca
     return out
 
 
-class HaloTable(object):
-    """Halo tables of one kernel map (pbn_halo_build): per tile of 128 output rows the distinct input rows, the map as
-    16-bit slots into that list and the per-offset fragment masks (csrc/spconv_halo.hip)."""
-
-    TILE_ROWS = 128
-
-    def __init__(self, nbr, n_out=None, tile_rows=TILE_ROWS, max_rows=0):
-        import ctypes
-        N.require_cuda(nbr)
-        assert nbr.dtype == torch.int32 and nbr.is_contiguous() and nbr.dim() == 2
-        self.nbr = nbr
-        self.n_out = int(nbr.shape[0]) if n_out is None else int(n_out)
-        self.layout = N.HaloLayout()
-        nbytes = N.lib().pbn_halo_bytes(self.n_out, int(nbr.shape[1]), int(tile_rows), ctypes.byref(self.layout))
-        assert nbytes > 0
-        self.table = torch.empty(nbytes, dtype=torch.uint8, device=nbr.device)
-        job = N.HaloJob()
-        job.nbr = nbr.data_ptr(); job.n_out_dev = None; job.table = self.table.data_ptr(); job.layout = self.layout
-        job.n_out = self.n_out; job.max_rows = int(max_rows)
-        N.check(N.lib().pbn_halo_build((N.HaloJob * 1)(job), 1, N.current_stream()), "pbn_halo_build")
-
-    def view(self, name, dtype, count):
-        off = getattr(self.layout, name)
-        return self.table[off:off + count * torch.empty(0, dtype=dtype).element_size()].view(dtype)
-
-    def counts(self):
-        return self.view("cnt", torch.int32, self.layout.tiles)
-
-
-def spconv_forward_halo(feats, halo, packed, scale=None, shift=None, residual=None, relu=False, out=None, lds_slots=0, cfg=0):
-    """pbn_spconv_forward_halo: the convolution over a map with halo tables (LDS-staged rows)."""
-    import ctypes
-    w, vpo, n_steps, cout_p = packed
-    dtype = feats.dtype
-    nbr, n_out = halo.nbr, halo.n_out
-    k = int(nbr.shape[1])
-    assert feats.stride(1) == 1 and feats.shape[1] >= vpo * _ELEMS[dtype]
-    if out is None:
-        out = torch.empty(n_out, cout_p, dtype=dtype, device=feats.device)
-    rc = N.lib().pbn_spconv_forward_halo(
-        N.c_vp(feats.data_ptr()), feats.stride(0), int(feats.shape[0]), N.c_vp(nbr.data_ptr()), k, None, n_out,
-        N.c_vp(w.data_ptr()), vpo, n_steps, cout_p, None if scale is None else N.c_vp(scale.data_ptr()),
-        None if shift is None else N.c_vp(shift.data_ptr()), None if residual is None else N.c_vp(residual.data_ptr()),
-        0 if residual is None else residual.stride(0), int(bool(relu)), N.c_vp(out.data_ptr()), out.stride(0), _DT[dtype],
-        N.c_vp(halo.table.data_ptr()), ctypes.byref(halo.layout), int(lds_slots), int(cfg), N.current_stream())
-    N.check(rc, "pbn_spconv_forward_halo")
-    return out
-
-
 def _pad_vec(v, cout_p, fill):
     out = torch.full((cout_p,), fill, dtype=torch.float32, device=v.device)
     out[:v.numel()] = v.reshape(-1).float()

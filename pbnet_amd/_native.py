@@ -39,23 +39,6 @@ class PrepareLayout(ctypes.Structure):
                 ("sort_temp_bytes", c_i64)]
 
 
-class HaloLayout(ctypes.Structure):
-    """pbn_halo_layout (include/pbnet_hip.h)."""
-    _fields_ = [("cnt", c_i64), ("rows", c_i64), ("loc", c_i64), ("fmask", c_i64),
-                ("tile_rows", c_i32), ("n_offsets", c_i32), ("pitch", c_i32), ("tiles", c_i32)]
-
-
-class HaloJob(ctypes.Structure):
-    """pbn_halo_job (include/pbnet_hip.h)."""
-    _fields_ = [("nbr", ctypes.c_void_p), ("n_out_dev", ctypes.c_void_p), ("table", ctypes.c_void_p), ("layout", HaloLayout),
-                ("n_out", c_i32), ("max_rows", c_i32)]
-
-
-class UnetHalo(ctypes.Structure):
-    """pbn_unet_halo (include/pbnet_hip.h)."""
-    _fields_ = [("table", ctypes.c_void_p * 5), ("layout", HaloLayout * 5)]
-
-
 class UnetOp(ctypes.Structure):
     """pbn_unet_op (include/pbnet_hip.h)."""
     _fields_ = [("map_kind", c_i32), ("level_in", c_i32), ("level_out", c_i32),
@@ -122,11 +105,6 @@ SIGNATURES = {
     "pbn_rs_table_build": (c_int, [c_i32p, c_int, c_i32p, c_int, c_vp, c_size, c_vp]),
     "pbn_spconv_forward_tab": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_int, c_vp, c_int, c_int, c_int, c_f32p, c_f32p,
                                        c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp, c_vp]),
-    "pbn_halo_bytes": (c_size, [c_int, c_int, c_int, ctypes.POINTER(HaloLayout)]),
-    "pbn_halo_build": (c_int, [ctypes.POINTER(HaloJob), c_int, c_vp]),
-    "pbn_spconv_forward_halo": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_int, c_vp, c_int, c_int, c_int, c_f32p,
-                                        c_f32p, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, ctypes.POINTER(HaloLayout), c_int,
-                                        c_int, c_vp]),
     "pbn_spconv_wgrad_workspace_bytes": (c_size, [c_int, c_int, c_int]),
     "pbn_spconv_wgrad": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_int,
                                  c_f32p, c_vp, c_size, c_vp]),
@@ -177,7 +155,6 @@ SIGNATURES = {
     "pbn_coords_prepare": (c_int, [c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(PrepareLayout), c_vp]),
     "pbn_coords_prepare_dev": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(PrepareLayout), c_vp]),
     "pbn_coords_prepare_hash": (c_int, [c_i32p, c_i32p, c_int, c_int, c_int, c_vp, c_size, ctypes.POINTER(PrepareLayout), c_vp]),
-    "pbn_unet_set_halo": (None, [ctypes.POINTER(UnetHalo)]),
     "pbn_unet_forward_dev": (c_int, [ctypes.POINTER(UnetOp), c_int, ctypes.POINTER(UnetBuf), c_int, ctypes.POINTER(c_i32),
                                      c_i32p, c_vp, c_int, ctypes.POINTER(ctypes.c_void_p), c_vp,
                                      ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_vp, c_size, c_int,

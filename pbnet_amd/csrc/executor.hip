@@ -218,37 +218,11 @@ extern "C" size_t pbn_unet_arena_bytes(const pbn_unet_buf* bufs, int n_bufs, con
     return off;
 }
 
-static thread_local const pbn_unet_halo* g_unet_halo = nullptr;
-extern "C" void pbn_unet_set_halo(const pbn_unet_halo* halo) { g_unet_halo = halo; }
-// the tables armed for this thread's next forward: taken (and disarmed) at the top of EVERY entry point, before any early return,
-// so that a failed call never leaves a pointer to a caller-owned struct behind for the next lineage
-static const pbn_unet_halo* take_halo() {
-    const pbn_unet_halo* h = g_unet_halo;
-    g_unet_halo = nullptr;
-    return h;
-}
-
-// Where the staged-row kernels pay (round 4, scripts/probe_halo.py with four streams on the bench scene's levels): K-split over
-// 64-row tiles on levels of 4 k - 20 k rows for every wide k = 3 layer up to 256 input channels (x1.2-1.5 in flight), on levels
-// of 2 k - 4 k rows for 128 / 256 input channels (x1.1-1.2; 384 -> 256 and the stride-16 level lose); a wave per 32 rows
-// (128-row tiles) on levels of 20 k - 70 k rows for 32-channel layers (x1.5).  PBN_UNET_HALO=0 switches it off.
-static bool halo_wanted(const pbn_unet_op& o, int rows, int tile_rows) {
-    static const int env = getenv("PBN_UNET_HALO") ? atoi(getenv("PBN_UNET_HALO")) : 1;
-    if (!env || o.map_kind != 1 || o.in2_buf >= 0 || (o.vpo & 3)) return false;
-    if (tile_rows == 64) {
-        if (rows >= 4000 && rows <= 20000) return o.vpo <= 32;
-        if (rows >= 2000 && rows < 4000) return o.vpo == 16 || o.vpo == 32;
-        return false;
-    }
-    if (tile_rows == 128) return rows >= 20000 && rows <= 70000 && o.vpo == 4;
-    return false;
-}
-
 static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs,
                              const int32_t* n_rows, const void* input, int ld_input, const int32_t* const* k3,
                              const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
                              size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream,
-                             hipEvent_t* events, const pbn_unet_halo* halo, const int32_t* n_rows_dev = nullptr) {
+                             hipEvent_t* events, const int32_t* n_rows_dev = nullptr) {
     if (!ops || !bufs || !n_rows || !input || !arena || n_ops < 1 || n_bufs < 2 || n_bufs > 512) return PBN_ERR_ARG;
     int64_t offs[512];
     if (pbn_unet_arena_bytes(bufs, n_bufs, n_rows, dtype, offs) > arena_bytes) return PBN_ERR_WORKSPACE;
@@ -331,16 +305,7 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
             g_rs_table = RsTableRef{nbr, rs_tab[l], n_rows[l]};
         }
         int rc = PBN_ERR_UNSUPPORTED;
-        if (halo && o.map_kind == 1 && halo->table[o.level_out] &&
-            halo_wanted(o, n_rows[o.level_out], halo->layout[o.level_out].tile_rows)) {
-            rc = pbn_spconv_forward_halo(in, ld(o.in_buf), n_rows[o.level_in], nbr, K, n_rows_dev ? n_rows_dev + o.level_out : nullptr,
-                                         n_rows[o.level_out], o.w, o.vpo, o.n_steps, o.cout_p, o.scale, o.shift, res,
-                                         o.res_buf >= 0 ? ld(o.res_buf) : 0, o.relu, out, ld(o.out_buf), dtype,
-                                         halo->table[o.level_out], &halo->layout[o.level_out], 0, 0, stream);
-        }
-        if (rc != PBN_ERR_UNSUPPORTED) {
-            // ran on the staged-row kernels (or failed there for another reason: reported below)
-        } else if (o.in2_buf >= 0) {           // a BasicBlock's 1x1 shortcut folded into this convolution's reduction
+        if (o.in2_buf >= 0) {           // a BasicBlock's 1x1 shortcut folded into this convolution's reduction
             if (o.in2_buf >= n_bufs) return PBN_ERR_ARG;
             const void* in2 = base(o.in2_buf) + (size_t)o.in2_col * es;
             rc = pbn_spconv_forward_dual(in, ld(o.in_buf), n_rows[o.level_in], nbr, K,
@@ -365,7 +330,7 @@ extern "C" int pbn_unet_forward(const pbn_unet_op* ops, int n_ops, const pbn_une
                                 const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
                                 size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream) {
     return unet_forward_impl(ops, n_ops, bufs, n_bufs, n_rows, input, ld_input, k3, k5, down, up, arena, arena_bytes, dtype,
-                             splitk_ws, splitk_bytes, stream, nullptr, take_halo());
+                             splitk_ws, splitk_bytes, stream, nullptr);
 }
 
 // capacity form: n_rows are capacities, the rows that exist are n_rows_dev[level] (device); launches are sized by the
@@ -375,10 +340,9 @@ extern "C" int pbn_unet_forward_dev(const pbn_unet_op* ops, int n_ops, const pbn
                                     const int32_t* const* k3, const int32_t* k5, const int32_t* const* down,
                                     const int32_t* const* up, void* arena, size_t arena_bytes, int dtype, void* splitk_ws,
                                     size_t splitk_bytes, pbn_stream_t stream) {
-    const pbn_unet_halo* halo = take_halo();          // consumed by THIS call whatever it returns
     if (!n_rows_dev) return PBN_ERR_ARG;
     return unet_forward_impl(ops, n_ops, bufs, n_bufs, n_rows_cap, input, ld_input, k3, k5, down, up, arena, arena_bytes, dtype,
-                             splitk_ws, splitk_bytes, stream, nullptr, halo, n_rows_dev);
+                             splitk_ws, splitk_bytes, stream, nullptr, n_rows_dev);
 }
 
 // Measurement variant: brackets every op with HIP events on the launching stream, SYNCHRONISES the stream at the end and
@@ -388,7 +352,6 @@ extern "C" int pbn_unet_forward_timed(const pbn_unet_op* ops, int n_ops, const p
                                       const int32_t* k5, const int32_t* const* down, const int32_t* const* up,
                                       void* arena, size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes,
                                       pbn_stream_t stream, float* op_ms) {
-    const pbn_unet_halo* halo = take_halo();          // consumed by THIS call whatever it returns
     if (!op_ms || n_ops < 1 || n_ops > 4096) return PBN_ERR_ARG;
     hipEvent_t* ev = new hipEvent_t[2 * (size_t)n_ops];
     int made = 0, rc = PBN_OK;
@@ -396,7 +359,7 @@ extern "C" int pbn_unet_forward_timed(const pbn_unet_op* ops, int n_ops, const p
         if (hipEventCreate(&ev[made]) != hipSuccess) { rc = PBN_ERR_HIP; break; }
     if (rc == PBN_OK)
         rc = unet_forward_impl(ops, n_ops, bufs, n_bufs, n_rows, input, ld_input, k3, k5, down, up, arena, arena_bytes,
-                               dtype, splitk_ws, splitk_bytes, stream, ev, halo);
+                               dtype, splitk_ws, splitk_bytes, stream, ev);
     if (rc == PBN_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = PBN_ERR_HIP;
     if (rc == PBN_OK)
         for (int i = 0; i < n_ops; ++i)

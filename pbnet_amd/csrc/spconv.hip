@@ -513,7 +513,7 @@ int launch_one(const ConvArgs& a, int ngroups, float* ws, size_t wsb, hipStream_
     // RING = 3 (two weight tiles in flight): experiment switch PBN_CONV_RING=3 for the small levels (< 8k rows)
     static const int ring_env = getenv("PBN_CONV_RING") ? atoi(getenv("PBN_CONV_RING")) : 2;
     // 8-wave workgroups (256 rows at NF = 2 share one weight ring: half the weight DMA per row).  Measured round 4
-    // (scripts/probe_halo.py, PBN_CONV_WAVES8=1): SLOWER everywhere -- L0 96->96 89 -> 106 us, L1 96->96 38 -> 56, L1 32->32 17 ->
+    // (round 4, PBN_CONV_WAVES8=1): SLOWER everywhere -- L0 96->96 89 -> 106 us, L1 96->96 38 -> 56, L1 32->32 17 ->
     // 26: the ring's barrier then spans 8 waves and the weight stream was not what bound the kernel.  Off by default.
     // PBN_CONV_WAVES8: 0 never (default), 1 always, else the row count from which they are used
     static const long long w8_env = getenv("PBN_CONV_WAVES8") ? atoll(getenv("PBN_CONV_WAVES8")) : 0;

@@ -180,14 +180,4 @@ bool rs_family_wanted(const ConvArgs& a, int dtype);
 bool rs_staged_pays(int n_out, int ntiles_total);      // a k = 3 cube map of this size is worth its tables (pbn_rs_table_build)
 int launch_rs(const ConvArgs& a, int dtype, int cfg, hipStream_t stream);
 
-// spconv_halo.hip: LDS-staged family over halo tables (pbn_halo_build); PBN_ERR_UNSUPPORTED when the shape is not built
-bool halo_supported(const ConvArgs& a, int tile_rows);
-int launch_halo(const ConvArgs& a, int dtype, const int* cnt, const int* rows, const unsigned short* loc,
-                const unsigned short* fmask, int tile_rows, int pitch, int lds_slots, int cfg, hipStream_t stream);
-
-// spconv_wave_halo.hip: the wave-autonomous family with LDS-staged rows; cfg = 1000 * ksplit + 100 * NF + NT as spconv_wave.hip
-int wh_tile_rows(int cfg);
-int launch_wave_halo(const ConvArgs& a, int dtype, const int* cnt, const int* rows, const unsigned short* loc,
-                     const unsigned short* fmask, int tile_rows, int pitch, int lds_slots, int cfg, int depth, hipStream_t stream);
-
 }  // namespace pbn

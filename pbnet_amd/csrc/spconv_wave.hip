@@ -559,7 +559,7 @@ int pick_cfg(const ConvArgs& a) {
     // (146 k rows: 44.8 us against 68.1 for 64 rows and 72.6 for the workgroup-tile kernel)
     if (a.vpo <= 2 && a.K >= 64 && ntt % 2 == 0) return 1202;
     // the k = 5 stems of the local-scene networks (32 / 64-byte... 64 / 128-byte input rows, 125 offsets, 58 k rows): the same
-    // shape wins there (round 4, scripts/probe_halo.py: 146 k rows 32->32 152 -> 90 us, 64->32 179 -> 156 against the
+    // shape wins there (round 4: 146 k rows 32->32 152 -> 90 us, 64->32 179 -> 156 against the
     // workgroup-tile kernel, whose 125-column rulebook tile leaves it two workgroups per CU)
     // round 4: their K-split over the tile's POPULATED steps (KLIST, 2202): 146 k-row probe 40->32 170 -> 154 us; level on 32->32
     // (94 / 95) and a loss on the 16-byte-row stem above, where a step spans four offsets and nearly every step is populated

@@ -319,58 +319,6 @@ class MinkUNet(nn.Module):
             self._plans[dtype] = hit
         return hit[1]
 
-    # round 4: per-tile tables of distinct input rows for the levels where the staged-row kernels win (csrc/executor.hip:
-    # halo_wanted).  Measured end to end on one box, alternating runs (PBNET_HALO=1 / 0): the 138 convolution ops of a scene alone
-    # 3 414 -> 3 304 us, but the forward 5.41 -> 5.50 ms and 342-346 -> 333-338 scenes/s with four in flight: the three table builds
-    # per forward (one launch + ~25 us of host work per lineage) cost more than the 40 layers that use them give back.  OFF by default.
-    HALO = os.environ.get("PBNET_HALO", "0") != "0"
-
-    @staticmethod
-    def _halo_tile_rows(rows):
-        if 2000 <= rows <= 20000:
-            return 64
-        if 20000 < rows <= 70000:
-            return 128
-        return 0
-
-    def _halo_tables(self, pyr, rows, k3_ptrs, n_rows_dev=None):
-        """(pbn_unet_halo struct, keep-alive) for this lineage, built by ONE launch and cached on the pyramid; None if no level
-        qualifies."""
-        import ctypes
-        from .. import _native as N
-        hit = pyr.__dict__.get("_halo_tables")
-        if hit is not None:
-            return hit if hit[0] is not None else None
-        lib = N.lib()
-        levels = [(l, self._halo_tile_rows(int(rows[l]))) for l in range(5)]
-        levels = [(l, t) for l, t in levels if t]
-        if not levels:
-            pyr.__dict__["_halo_tables"] = (None, None)
-            return None
-        lays, sizes = {}, {}
-        for l, t in levels:
-            lays[l] = N.HaloLayout()
-            sizes[l] = int(lib.pbn_halo_bytes(int(rows[l]), 27, t, ctypes.byref(lays[l])))
-        total = sum((sizes[l] + 255) // 256 * 256 for l, _ in levels)
-        arena = torch.empty(total, dtype=torch.uint8, device=pyr.device)
-        jobs = (N.HaloJob * len(levels))()
-        st = N.UnetHalo()
-        off = 0
-        for j, (l, t) in enumerate(levels):
-            jobs[j].nbr = k3_ptrs[l]
-            jobs[j].n_out_dev = None if n_rows_dev is None else n_rows_dev + 4 * l
-            jobs[j].table = arena.data_ptr() + off
-            jobs[j].layout = lays[l]
-            jobs[j].n_out = int(rows[l])
-            jobs[j].max_rows = 0
-            st.table[l] = arena.data_ptr() + off
-            st.layout[l] = lays[l]
-            off += (sizes[l] + 255) // 256 * 256
-        N.check(lib.pbn_halo_build(jobs, len(levels), N.current_stream()), "pbn_halo_build")
-        hit = (st, arena)
-        pyr.__dict__["_halo_tables"] = hit
-        return hit
-
     def _forward_fused(self, x):
         import ctypes
         from .. import _native as N
@@ -411,9 +359,6 @@ class MinkUNet(nn.Module):
         args = (plan["ops"], plan["n_ops"], plan["bufs"], plan["n_bufs"], n_rows, vp(feats.data_ptr()), feats.stride(0),
                 (vp * 5)(*k3), vp(k5), (vp * 4)(*down), (vp * 4)(*up), vp(arena.data_ptr()), nbytes, _DT[dt],
                 vp(ws.data_ptr()), ws.numel(), N.current_stream())
-        halo = self._halo_tables(pyr, rows, k3) if (self.HALO and sv is not None) else None
-        if halo is not None:
-            lib.pbn_unet_set_halo(ctypes.byref(halo[0]))
         if MinkUNet.OP_TIMING_SINK is None:
             rc = lib.pbn_unet_forward(*args)
         else:  # bench.py's roofline probe: per-op HIP-event durations (synchronises)

@@ -1,6 +1,6 @@
 """GPU tier: the benchmarked mode under stress -- random scenes of different sizes evaluated by 4 host threads on their own HIP
 streams, 6 rounds in shuffled order, bf16 slabs (what `bench.py --inflight 4` does): every in-flight result must equal the
-stand-alone result bit for bit.  Runs tests/fuzz_inflight.py in its own process (it sets GPU_MAX_HW_QUEUES before the HIP
+stand-alone result bit for bit.  Runs scripts/fuzz_inflight.py in its own process (it sets GPU_MAX_HW_QUEUES before the HIP
 runtime starts, as bench.py does)."""
 import os
 import subprocess
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_four_streams_six_rounds_bit_identical():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_inflight.py"), "6", "4", "6"], capture_output=True,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_inflight.py"), "6", "4", "6"], capture_output=True,
                        text=True, timeout=900)
     print(p.stdout[-2000:])
     print(p.stderr[-2000:])
