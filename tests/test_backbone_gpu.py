@@ -516,8 +516,8 @@ def test_folded_shortcuts_equal_separate_launches(arch):
 
 
 def test_fold_guard_extreme_batchnorm_statistics():
-    """the folded shortcut multiplies BatchNorm scales into 16-bit weights.  With a running variance of 1e-12
-    (scale ~1e6) the products leave fp16's range: the planner must keep such a block on the separate launches (scales in the fp32
+    """the folded shortcut multiplies BatchNorm scales into 16-bit weights.  With a huge gamma (scale ~1e7) or a
+    running variance of 1e12 (scale ~1e-6) the products leave fp16's normal range: the planner must keep such a block on the separate launches (scales in the fp32
     epilogue) -- the fp16 forward stays finite and equals the forward with folding switched off, bit for bit; bf16 keeps folding."""
     from pbnet_amd.network.mink_unet import MinkUNet
     coords = _scene_coords(53, room=(0.8, 0.6, 0.5), batch=1)
@@ -527,7 +527,12 @@ def test_fold_guard_extreme_batchnorm_statistics():
     assert blocks
     with torch.no_grad():
         for i, blk in enumerate(blocks):
-            (blk.norm2 if i % 2 == 0 else blk.downsample[1]).bn.running_var.fill_(1e-12 if i % 4 < 2 else 1e12)
+            bn = (blk.norm2 if i % 2 == 0 else blk.downsample[1]).bn
+            if i % 4 < 2:
+                bn.weight.fill_(3e6)                 # gamma / sqrt(var + eps) ~ 1e9: the scaled weights overflow fp16
+                bn.running_var.fill_(1e-2)
+            else:
+                bn.running_var.fill_(1e12)           # scale ~ 1e-6: the scaled weights are fp16 subnormals
     for blk in blocks:
         assert not net._fold_is_safe(blk, torch.float16)
         assert net._fold_is_safe(blk, torch.bfloat16)
