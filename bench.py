@@ -57,7 +57,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_SUMMARIES = ("r04_d_pmc_summary.json", "r04_c_pmc_summary.json", "r04_b_pmc_summary.json", "r04_a_pmc_summary.json", "r03_c_pmc_summary.json", "r03_b_pmc_summary.json", "r03_a_pmc_summary.json", "r02_b_pmc_summary.json", "r02_a_pmc_summary.json", "r01_pmc_summary.json")   # newest first
+PMC_SUMMARIES = ("r05_b_pmc_summary.json", "r05_a_pmc_summary.json", "r04_d_pmc_summary.json", "r04_c_pmc_summary.json", "r04_b_pmc_summary.json", "r04_a_pmc_summary.json", "r03_c_pmc_summary.json", "r03_b_pmc_summary.json", "r03_a_pmc_summary.json", "r02_b_pmc_summary.json", "r02_a_pmc_summary.json", "r01_pmc_summary.json")   # newest first
 
 
 WORKLOADS = {
@@ -344,6 +344,27 @@ def pmc_traffic(args):
         except (OSError, KeyError, ValueError):
             continue
     return None, None
+
+
+def gpu_active(args):
+    """gpu_active_frac: union of kernel intervals / wall from the newest committed kernel-trace summary of
+    this command line (scripts/profile_round.sh -> profiles/<tag>_bench_concurrency.json for the in-flight mode,
+    <tag>_inflight1_concurrency.json for one scene alone).  A trace cannot be taken from inside the process."""
+    if args.copies != 1 or args.dtype != "bf16" or args.workload != "c2":
+        return None
+    out = {}
+    for tag in ("r05_b", "r05_a"):
+        for key, name in (("in_flight", "%s_bench_concurrency.json" % tag), ("one_scene", "%s_inflight1_concurrency.json" % tag)):
+            if key in out:
+                continue
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    d = json.load(f)
+                out[key] = {"gpu_active_frac": d["gpu_active_frac"], "mean_kernels_running": d["mean_kernels_running"],
+                            "source": "profiles/" + name}
+            except (OSError, KeyError, ValueError):
+                continue
+    return out or None
 
 
 def cpu_baseline(cfg, model, raw, runs=3):
@@ -819,6 +840,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic room scene (pbnet_amd/synth.py), random-init weights (seed 22), teacher-forced "
                     "semantic/offset head outputs",
+            "gpu_active": gpu_active(args),
             "timed_blocks": {"n": len(blocks), "steps_per_block": args.steps, "timed_seconds": round(float(sum(blocks)), 3),
                              "cv": round(float(np.std(blocks) / np.mean(blocks)), 4),
                              "statistic": "median", "value_p10": round(rate(float(np.percentile(blocks, 90))), 3),

@@ -58,3 +58,13 @@ tot = sum(ksec.values())
 print("%-42s %8s %8s %8s" % ("family", "k-sec %", "alone ms", "alone %wall"))
 for k, v in ksec.most_common(22):
     print("%-42s %7.1f%% %8.2f %7.1f%%" % (k, 100 * v / tot, alone[k] / 1e6, 100 * alone[k] / wall))
+# machine-readable summary next to the text (bench.py reports gpu_active_frac from the newest committed one)
+import json, os
+out_json = os.environ.get("PBN_TRACE_JSON")
+if out_json:
+    with open(out_json, "w") as fh:
+        json.dump({"what": "union of kernel intervals / wall over the middle of a rocprofv3 --kernel-trace run of bench.py (profiler attached: "
+                           "the run is slower than the plain one)", "window_ms": round(wall / 1e6, 2), "kernels": len(ev),
+                   "gpu_active_frac": round(1 - hist[0] / wall, 4),
+                   "concurrency_share_of_wall": {str(k): round(v / wall, 4) for k, v in sorted(hist.items())},
+                   "mean_kernels_running": round(sum(k * v for k, v in hist.items()) / wall, 3)}, fh, indent=1)

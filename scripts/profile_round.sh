@@ -16,17 +16,19 @@ cd $R
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 timeout 600 python bench.py 2> $O/bench.err | grep "^{" > $O/${TAG}_bench.json; tail -1 $O/${TAG}_bench.json | cut -c1-200
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --no-extras > $O/kt.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-extras --inflight 1 > $O/kt1.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --no-extras --min-seconds 0.5 > $O/kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-extras --inflight 1 --min-seconds 0.5 > $O/kt1.log 2>&1
+PBN_TRACE_JSON=$O/${TAG}_bench_concurrency.json python scripts/analyze_trace.py $(find $O/kt -name "*kernel_trace.csv" | head -1) > $O/${TAG}_bench_concurrency.txt 2>&1; head -3 $O/${TAG}_bench_concurrency.txt
+PBN_TRACE_JSON=$O/${TAG}_inflight1_concurrency.json python scripts/analyze_trace.py $(find $O/kt1 -name "*kernel_trace.csv" | head -1) > $O/${TAG}_inflight1_concurrency.txt 2>&1; head -3 $O/${TAG}_inflight1_concurrency.txt
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv
 cp $(find $O/kt1 -name "*kernel_stats.csv" | head -1) $O/${TAG}_inflight1_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pmc_$c
-  timeout 900 rocprofv3 --pmc $c --output-format csv -d $d -o bench -- python bench.py --no-extras --steps 5 --warmup 2 --repeats 1 > $O/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d $d -o bench -- python bench.py --no-extras --steps 5 --warmup 2 --repeats 1 --min-seconds 0 > $O/pmc_$c.log 2>&1
   mkdir -p /tmp/pmc_flat_$c && cp $(find $d -name "bench_counter_collection.csv" | head -1) /tmp/pmc_flat_$c/bench_counter_collection.csv
 done
 python scripts/summarize_pmc.py /tmp/pmc_flat_FETCH_SIZE /tmp/pmc_flat_WRITE_SIZE $O/${TAG}_pmc_summary.json > $O/pmc_summary.log 2>&1; tail -3 $O/pmc_summary.log
-timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_sq -o sq -- python bench.py --no-extras --inflight 1 --steps 5 --warmup 2 --repeats 1 > $O/pmc_sq.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_sq -o sq -- python bench.py --no-extras --inflight 1 --steps 5 --warmup 2 --repeats 1 --min-seconds 0 > $O/pmc_sq.log 2>&1
 python scripts/summarize_sq.py $(find /tmp/pmc_sq -name "sq_counter_collection.csv" | head -1) $(find /tmp/pmc_sq -name "sq_kernel_trace.csv" | head -1) $O/${TAG}_sq_conv_summary.json > $O/sq_summary.log 2>&1; tail -12 $O/sq_summary.log
 # the training step of configs[2]: its line and its kernel table
 timeout 300 python scripts/train_step.py --steps 8 --warmup 2 --phases 2> $O/train_step.err | grep "^{" > $O/${TAG}_train_step.json; tail -1 $O/${TAG}_train_step.json | cut -c1-200; grep phases $O/train_step.err

@@ -16,7 +16,7 @@ import sys
 def family(name):
     if "k_spconv_reduce" in name:
         return "k_spconv_reduce"
-    if "k_spconv<" in name or "k_spconv_wave<" in name:      # both convolution kernel families
+    if "k_spconv<" in name or "k_spconv_wave<" in name or "k_spconv_rs<" in name or "k_spconv_rsh<" in name:      # every convolution kernel family
         return "k_spconv"
     if "pbn::" in name:
         return "pbn_other"

@@ -19,6 +19,10 @@ def group(name, grid):
         return "reduce"
     if "k_spconv_wave<" in name:
         return "wave_family"
+    if "k_spconv_rsh<" in name:
+        return "row_stationary_staged"
+    if "k_spconv_rs<" in name:
+        return "row_stationary_gather"
     if "k_spconv<" in name:
         return "tile_family_wide" if grid >= 400 * 256 else "tile_family_coarse"
     return None
