@@ -36,7 +36,7 @@ constexpr int RS_NF_MAX = 5;          // fragments per wave: 8 x 5 x 16 = 640 ro
 constexpr unsigned RS_OOB = 0x80000000u;
 
 template <typename T, int NF, int NT, int CG, int RING>
-__global__ __launch_bounds__(RS_TPB) void k_spconv_rs(const ConvArgs a, const int tile_rows, const int n_tiles, const int list_cap) {
+__global__ __launch_bounds__(RS_TPB) void k_spconv_rs(const ConvArgs a, const int tile_rows_launch, const int n_tiles, const int list_cap) {
     static_assert(Tr<T>::ELEMS * sizeof(T) == 16, "one gather vector is 16 bytes");
     constexpr int DEPTH = RING - 1;                         // weight tiles in flight ahead
     constexpr int PW = (CG * NT + RS_NW - 1) / RS_NW;        // weight pieces (1 KiB) per wave and group
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rs(const ConvArgs a, const in
     const int K = a.K, KS = K | 1;
     u32x4* s_w = reinterpret_cast<u32x4*>(smem);                                        // RING slots x CG * NT KiB
     int* s_nbr = reinterpret_cast<int*>(smem + (size_t)RING * CG * NT * 1024);          // tile_rows * KS
-    int* s_gko = s_nbr + ((tile_rows * KS + 3) & ~3);                                    // list_cap: offset | sub-group << 16
+    int* s_gko = s_nbr + ((tile_rows_launch * KS + 3) & ~3);                             // list_cap: offset | sub-group << 16
     unsigned* s_act = reinterpret_cast<unsigned*>(s_gko + list_cap);                     // [0..1] active offsets, [2] groups
     float* s_ss = reinterpret_cast<float*>(s_act + 4);                                   // scale | shift
 
@@ -52,6 +52,9 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rs(const ConvArgs a, const in
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, rl = lane & 15;
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
+    // capacity form (n_out is a capacity, the rows that exist are counted on the device): the launch's tiles share the rows that
+    // exist -- a tile height sized by the capacity would leave the last workgroups without work and the others with too much
+    const int tile_rows = a.n_out_dev ? min(tile_rows_launch, (((n + n_tiles - 1) / n_tiles) + 15) & ~15) : tile_rows_launch;
     const int tile = xcd_tile(blockIdx.x, n_tiles);
     const int row0 = tile * tile_rows;
     if (row0 >= n) return;
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(RS_TPB) void k_rs_table_build(const int* __restrict
 }
 
 template <typename T, int NF, int NT, int BO, bool ABL = false>
-__global__ __launch_bounds__(RS_TPB) void k_spconv_rsh(const ConvArgs a, const int tile_rows, const int n_tiles, const int s_cap,
+__global__ __launch_bounds__(RS_TPB) void k_spconv_rsh(const ConvArgs a, const int tile_rows_launch, const int n_tiles, const int s_cap,
                                                        const int n_in, const int n_in2) {
     static_assert(Tr<T>::ELEMS * sizeof(T) == 16, "one gather vector is 16 bytes");
     static_assert(BO % 4 == 0, "a batch is whole 8-byte groups of slot-table columns");
@@ -683,7 +686,7 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rsh(const ConvArgs a, const i
     static_assert(PWB <= BO, "a wave issues at most one weight piece per step");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = a.K, KP = (K + BO - 1) / BO * BO;
-    const RshLds L = rsh_layout(tile_rows, K, s_cap, NT, BO);
+    const RshLds L = rsh_layout(tile_rows_launch, K, s_cap, NT, BO);
     unsigned short* s_slot = reinterpret_cast<unsigned short*>(smem + L.slots);
     u32x4* s_w = reinterpret_cast<u32x4*>(smem + L.wring);
     int* s_extra = reinterpret_cast<int*>(smem + L.extra);
@@ -694,6 +697,8 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rsh(const ConvArgs a, const i
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, rl = lane & 15;
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
+    // capacity form: the launch's tiles share the rows that exist (see k_spconv_rs); the LDS layout stays the launch's
+    const int tile_rows = a.n_out_dev ? min(tile_rows_launch, (((n + n_tiles - 1) / n_tiles) + 15) & ~15) : tile_rows_launch;
     const int tile = xcd_tile(blockIdx.x, n_tiles);
     const int row0 = tile * tile_rows;
     if (row0 >= n) return;
@@ -1115,10 +1120,10 @@ int rs_cg(const ConvArgs& a) {
 
 }  // namespace
 
-// Where each form pays (MI355X, bench scene, bf16).  Single layers from a HIP graph (scripts/probe_rs.py, gpurun_out/r05_probe_rs_10.txt):
+// Where each form pays (MI355X, bench scene, bf16).  Single layers from a HIP graph (scripts/probe_rs.py, profiles/r05_probe_rs.txt):
 // k = 3 cube maps with the map's tables, staged form: 96->96 at 146 k rows 96.5 -> 74.6 us (gather form 82.1), 128->96 135.8 -> 91.6,
 // 32->32 at 57 k rows 21.4 -> 16.2; 96 channels at 57 k rows only draws (tiles of 240 rows: the weights are streamed per 240 rows again).
-// Inside the pipeline (scripts/op_table.py, gpurun_out/r05_op_table_*.txt; scripts/ab_rs.sh: alternating bench runs on one box) the
+// Inside the pipeline (scripts/op_table.py, profiles/r05_op_table_*.txt; scripts/ab_rs.sh: alternating bench runs on one box) the
 // tables do not earn their build: the first layer of a level pays ~20-25 us for them, the three to five layers that follow give
 // back 5-8 us each -- convolution ops of one scene 3 490 us (k_spconv) -> 3 332 (tables) / 3 340 (none), and with four scenes in
 // flight 330-332 scenes/s (k_spconv) -> 325-335 (tables) / 341-342 (none).  So by default no tables are built
