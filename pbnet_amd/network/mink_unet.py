@@ -11,6 +11,7 @@ Two execution paths over the same parameters:
     block stores its result directly into the right-hand columns of the decoder's concat slab, the transposed
     convolution into the left-hand columns), so no activation is touched twice.
 """
+import operator
 import os
 
 import torch
@@ -48,6 +49,9 @@ def _group_steps(spo):
         if spo % c == 0:
             return c
     return 1
+
+
+_VERSION_OF = operator.attrgetter("_version")
 
 
 class MinkUNet(nn.Module):
@@ -312,7 +316,9 @@ class MinkUNet(nn.Module):
         if tensors is None:
             tensors = list(self.parameters()) + list(self.buffers())
             self.__dict__["_state_tensors"] = tensors
-        ver = tuple([t._version for t in tensors])
+        # versions only grow, so their SUM changes whenever any of them does: one C-level pass, no list / tuple per forward
+        # (round 5: the walk was 0.23 ms of the ~3 ms of Python per forward that the in-flight rate is bound by)
+        ver = sum(map(_VERSION_OF, tensors))
         hit = self._plans.get(dtype)
         if hit is None or hit[0] != ver:
             hit = (ver, self._build_plan(dtype))
