@@ -327,10 +327,13 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rs(const ConvArgs a, const in
 // switched off still takes 70 % of the full time -- the path is bound by the NUMBER of vector-memory instructions, and an
 // output-stationary tile issues 27 x 3 of them per fragment to fetch rows of which it names only ~1.35 distinct ones per output
 // row.  Here every distinct input row of the tile enters the CU ONCE per 64-byte piece:
-//   * prologue: the rulebook tile is read into LDS; entries inside the tile's WINDOW of consecutive input rows (cube maps: the
-//     tile's own rows; strided / transposed maps: the rows from the tile's smallest entry on) become slot = row - window start,
-//     the others are de-duplicated through an LDS hash set (atomicCAS, linear probing) and numbered behind the window; the map
-//     is rewritten as 16-bit slots;
+//   * prologue (rsh_build_tile; or once per map: k_rs_table_build): a thread's rulebook entries go global -> registers with all
+//     loads in flight; entries inside the tile's WINDOW of consecutive input rows (cube maps: the tile's own rows; strided /
+//     transposed maps: the rows from the tile's smallest entry on) become slot = row - window start, the others are de-duplicated
+//     through an LDS hash set (atomicCAS, linear probing), numbered behind the window and renumbered by row value (which rows share
+//     a stage segment must not depend on timing); the tile's rows are counting-sorted by their 8 corner-offset bits (rows of a
+//     fragment then share most of their neighbour pattern); the map is rewritten, by POSITION in that order, as the 16-bit stage
+//     position of each neighbour's slot, and per wave and offset the mask of fragments that have a neighbour there is collected;
 //   * the reduction runs PIECE-major: for each 64-byte piece c of the input rows (32 bf16 channels) the pieces of all staged
 //     rows are copied global -> LDS by the DMA path (quad-coalesced: four lanes fetch one row's piece; chunk g of slot s sits at
 //     position (g + 2 (s / 4)) & 3 of its 64 bytes: with that rotation the four lane groups of a ds_read_b128 -- {0-3, 12-15,
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(RS_TPB) void k_rs_table_build(const int* __restrict
     for (int e = tid; e < (int)(R.total >> 4); e += RS_TPB) dst[e] = src[e];
 }
 
-template <typename T, int NF, int NT, int BO, bool ABL = false>
+template <typename T, int NF, int NT, int BO>
 __global__ __launch_bounds__(RS_TPB) void k_spconv_rsh(const ConvArgs a, const int tile_rows_launch, const int n_tiles, const int s_cap,
                                                        const int n_in, const int n_in2) {
     static_assert(Tr<T>::ELEMS * sizeof(T) == 16, "one gather vector is 16 bytes");
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rsh(const ConvArgs a, const i
                 unsigned t = (j & 1) ? (d >> 16) : (d & 0xffffu);            // position of the slot, or 0xffff
                 t = min(t - seg_pos, zp);
                 const unsigned ad = (((t + (unsigned)g) & 3u) | (t & ~3u)) << 4;
-                x[f] = (ABL && (a.dbg & 4)) ? u32x4{ad, ad, ad, ad} : *reinterpret_cast<const u32x4*>(smem + stage_off + ad);
+                x[f] = *reinterpret_cast<const u32x4*>(smem + stage_off + ad);
             }
         };
         // software pipeline over the steps of the pass: the operands of step i + 1 are requested before the MFMAs of step i
@@ -889,7 +892,7 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rsh(const ConvArgs a, const i
             RSH_STAMP(7)   /* batch tail */
             asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
             RSH_STAMP(8)   /* wait for own DMA */
-            if (!(ABL && (a.dbg & 512))) __syncthreads();  // batch b (and the stage) has landed everywhere; slot (b + 1) & 1 is free
+            __syncthreads();                               // batch b (and the stage) has landed everywhere; slot (b + 1) & 1 is free
             RSH_STAMP(9)   /* batch barrier */
             const u32x4* wb = s_w + (b & 1) * (BO * NT * 64);
             // the batch's offsets and this wave's fragment masks: scalars; the next batch's table entries: prefetched
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rsh(const ConvArgs a, const i
             u32x4 wfb[2][NT];
             if (fmv[0] != 0u) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) wfb[0][t] = (ABL && (a.dbg & 256)) ? u32x4{1u, 2u, 3u, 4u} : wb[t * 64 + lane];
+                for (int t = 0; t < NT; ++t) wfb[0][t] = wb[t * 64 + lane];
             }
 #pragma unroll
             for (int j = 0; j < BO; ++j) {
@@ -930,20 +933,15 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rsh(const ConvArgs a, const i
                 if (j + 1 < BO && fmv[j + 1] != 0u) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        wfb[(j + 1) & 1][t] = (ABL && (a.dbg & 256)) ? u32x4{1u, 2u, 3u, 4u} : wb[((j + 1) * NT + t) * 64 + lane];
+                        wfb[(j + 1) & 1][t] = wb[((j + 1) * NT + t) * 64 + lane];
                 }
                 if (j < PWB) dma_w_piece(b + 1, nb, second, c, j);      // the next batch's weights: one piece per step, not a burst
                 if (fmv[j] != 0u) {
-                    if (ABL && (a.dbg & 2)) {           // ablation: no MFMAs (the operands stay live through one cheap use)
 #pragma unroll
-                        for (int f = 0; f < NF; ++f) acc[f][0][0] += __uint_as_float(xbuf[j & 1][f][0] ^ wfb[j & 1][f % NT][1]);
-                    } else {
+                    for (int f = 0; f < NF; ++f) {
+                        if ((fmv[j] >> f) & 1u) {
 #pragma unroll
-                        for (int f = 0; f < NF; ++f) {
-                            if ((fmv[j] >> f) & 1u) {
-#pragma unroll
-                                for (int t = 0; t < NT; ++t) mfma_step<T>(wfb[j & 1][t], xbuf[j & 1][f], acc[f][t]);
-                            }
+                            for (int t = 0; t < NT; ++t) mfma_step<T>(wfb[j & 1][t], xbuf[j & 1][f], acc[f][t]);
                         }
                     }
                 }
@@ -1078,9 +1076,6 @@ int launch_rsh_one(const ConvArgs& a, const RsShape& s, hipStream_t stream) {
     if ((s_cap + 1) * 64 < RSH_SCRATCH_BYTES) return PBN_ERR_UNSUPPORTED;   // the prologue's arrays live in the stage region
     const RshLds L = rsh_layout(s.tile_rows, a.K, (int)s_cap, NT, BO);
     auto kern = k_spconv_rsh<T, NF, NT, BO>;
-    if constexpr (sizeof(T) == 2 && NT == 6 && (NF == 5 || NF == 2)) {
-        if (a.dbg & 0x1000) kern = k_spconv_rsh<T, NF, NT, BO, true>;      // ablation build of the fast loop (scripts/rsh_ablate.sh)
-    }
     if (L.total > 64 * 1024)
         PBN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
     const int esz = (int)sizeof(T);
@@ -1169,7 +1164,7 @@ int launch_rs(const ConvArgs& a, int dtype, int cfg, hipStream_t stream) {
         const bool gather_ok = !(a.ntiles_total == 6 && cg == 4 && sh.nf == 5);       // (that instantiation spills)
         staged = (cube && a.rs_table && rs_staged_pays(a.n_out, a.ntiles_total)) || !gather_ok;
     }
-    if (staged && (a.ntiles_total == 6 || a.ntiles_total == 2) && (!a.in2 || !(a.vpo2 & 3))) {
+    if (staged && a.nbr && (a.ntiles_total == 6 || a.ntiles_total == 2) && (!a.in2 || !(a.vpo2 & 3))) {
         const RsShape sh = rs_shape(a.n_out, cfg, force_rows);
         int rc = PBN_ERR_UNSUPPORTED;
         switch (dtype) {
@@ -1180,6 +1175,7 @@ int launch_rs(const ConvArgs& a, int dtype, int cfg, hipStream_t stream) {
         }
         if (rc != PBN_ERR_UNSUPPORTED) return rc;
     }
+    if (!a.nbr) return PBN_ERR_UNSUPPORTED;                    // identity maps (1x1 / linear) stay on the other families
     if (a.in2 && ((a.vpo2 & 3) || a.n_main % cg || a.n_steps % cg)) return PBN_ERR_UNSUPPORTED;
     if (!a.in2 && a.n_steps % cg) return PBN_ERR_UNSUPPORTED;
     ConvArgs b = a;
