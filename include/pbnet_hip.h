@@ -566,6 +566,10 @@ typedef struct {
 } pbn_unet_buf;
 
 size_t pbn_unet_arena_bytes(const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows, int dtype, int64_t* buf_offsets);
+/* Round 5: rows EXPECTED per level (5 ints, copied) for the next pbn_unet_forward_dev call of this thread, whose row counts are
+ * capacities: kernel families and tile shapes are then chosen for the rows expected (as the size-exact forward would choose them),
+ * grids for the capacities.  NULL disarms.  Consumed by the next pbn_unet_forward* call of the thread, whatever it returns. */
+void pbn_unet_set_rows_hint(const int32_t* rows);
 int pbn_unet_forward_dev(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs, const int32_t* n_rows_cap,
                          const int32_t* n_rows_dev, const void* input, int ld_input, const int32_t* const* k3,
                          const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,

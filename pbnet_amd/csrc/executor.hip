@@ -218,11 +218,27 @@ extern "C" size_t pbn_unet_arena_bytes(const pbn_unet_buf* bufs, int n_bufs, con
     return off;
 }
 
+// Rows expected per level for the NEXT forward of this thread whose row counts are capacities (pbn_unet_forward_dev): the values are
+// COPIED (nothing of the caller's is kept) and consumed at the top of every entry point, whatever it returns.
+static thread_local int g_unet_rows_hint[6] = {0, 0, 0, 0, 0, 0};      // [5] = armed
+extern "C" void pbn_unet_set_rows_hint(const int32_t* rows) {
+    for (int l = 0; l < 5; ++l) g_unet_rows_hint[l] = rows ? rows[l] : 0;
+    g_unet_rows_hint[5] = rows ? 1 : 0;
+}
+struct RowsHint { int rows[5]; bool armed; };
+static RowsHint take_rows_hint() {
+    RowsHint h;
+    for (int l = 0; l < 5; ++l) h.rows[l] = g_unet_rows_hint[l];
+    h.armed = g_unet_rows_hint[5] != 0;
+    g_unet_rows_hint[5] = 0;
+    return h;
+}
+
 static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_buf* bufs, int n_bufs,
                              const int32_t* n_rows, const void* input, int ld_input, const int32_t* const* k3,
                              const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
                              size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream,
-                             hipEvent_t* events, const int32_t* n_rows_dev = nullptr) {
+                             hipEvent_t* events, const int32_t* n_rows_dev = nullptr, const RowsHint* hint = nullptr) {
     if (!ops || !bufs || !n_rows || !input || !arena || n_ops < 1 || n_bufs < 2 || n_bufs > 512) return PBN_ERR_ARG;
     int64_t offs[512];
     if (pbn_unet_arena_bytes(bufs, n_bufs, n_rows, dtype, offs) > arena_bytes) return PBN_ERR_WORKSPACE;
@@ -253,7 +269,7 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
             splitk_bytes = (size_t)(end - (char*)splitk_ws);
         }
     }
-    struct RsGuard { ~RsGuard() { g_rs_table = RsTableRef{nullptr, nullptr, 0}; } } rs_guard;   // cleared on every return path
+    struct RsGuard { ~RsGuard() { g_rs_table = RsTableRef{nullptr, nullptr, 0}; g_rows_hint = 0; } } rs_guard;   // cleared on every return path
     auto base = [&](int b) -> char* { return b == 0 ? (char*)input : A + offs[b]; };
     auto ld = [&](int b) -> int { return b == 0 ? ld_input : bufs[b].width; };
     for (int i = 0; i < n_ops; ++i) {
@@ -284,7 +300,7 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
                 ConvArgs nx;
                 memset(&nx, 0, sizeof(nx));
                 nx.K = q.map_kind == 0 ? 1 : (q.map_kind == 1 ? 27 : (q.map_kind == 2 ? 125 : 8));
-                nx.vpo = q.vpo; nx.n_steps = q.n_steps; nx.ntiles_total = q.cout_p / 16; nx.n_out = n_rows[q.level_out];
+                nx.vpo = q.vpo; nx.n_steps = q.n_steps; nx.ntiles_total = q.cout_p / 16; nx.n_out = nx.n_sel = n_rows[q.level_out];
                 nx.w_bytes = (unsigned)((unsigned long long)q.n_steps * (q.cout_p / 16) * 1024ull);
                 nx.in_bytes = (unsigned)((unsigned long long)n_rows[q.level_in] * ld(q.in_buf) * es);
                 LaunchDesc d;
@@ -293,6 +309,7 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
             }
         }
         if (events) PBN_HIP_CHECK(hipEventRecord(events[2 * i], (hipStream_t)stream));
+        g_rows_hint = (hint && hint->armed && n_rows_dev) ? hint->rows[o.level_out] : 0;
         g_rs_table = RsTableRef{nullptr, nullptr, 0};
         if (o.map_kind == 1 && rs_tab[o.level_out] && rs_staged_pays(n_rows[o.level_out], o.cout_p / 16)) {
             const int l = o.level_out;
@@ -329,6 +346,7 @@ extern "C" int pbn_unet_forward(const pbn_unet_op* ops, int n_ops, const pbn_une
                                 const int32_t* n_rows, const void* input, int ld_input, const int32_t* const* k3,
                                 const int32_t* k5, const int32_t* const* down, const int32_t* const* up, void* arena,
                                 size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes, pbn_stream_t stream) {
+    (void)take_rows_hint();
     return unet_forward_impl(ops, n_ops, bufs, n_bufs, n_rows, input, ld_input, k3, k5, down, up, arena, arena_bytes, dtype,
                              splitk_ws, splitk_bytes, stream, nullptr);
 }
@@ -340,9 +358,10 @@ extern "C" int pbn_unet_forward_dev(const pbn_unet_op* ops, int n_ops, const pbn
                                     const int32_t* const* k3, const int32_t* k5, const int32_t* const* down,
                                     const int32_t* const* up, void* arena, size_t arena_bytes, int dtype, void* splitk_ws,
                                     size_t splitk_bytes, pbn_stream_t stream) {
+    const RowsHint hint = take_rows_hint();           // consumed by THIS call whatever it returns
     if (!n_rows_dev) return PBN_ERR_ARG;
     return unet_forward_impl(ops, n_ops, bufs, n_bufs, n_rows_cap, input, ld_input, k3, k5, down, up, arena, arena_bytes, dtype,
-                             splitk_ws, splitk_bytes, stream, nullptr, n_rows_dev);
+                             splitk_ws, splitk_bytes, stream, nullptr, n_rows_dev, &hint);
 }
 
 // Measurement variant: brackets every op with HIP events on the launching stream, SYNCHRONISES the stream at the end and
@@ -352,6 +371,7 @@ extern "C" int pbn_unet_forward_timed(const pbn_unet_op* ops, int n_ops, const p
                                       const int32_t* k5, const int32_t* const* down, const int32_t* const* up,
                                       void* arena, size_t arena_bytes, int dtype, void* splitk_ws, size_t splitk_bytes,
                                       pbn_stream_t stream, float* op_ms) {
+    (void)take_rows_hint();
     if (!op_ms || n_ops < 1 || n_ops > 4096) return PBN_ERR_ARG;
     hipEvent_t* ev = new hipEvent_t[2 * (size_t)n_ops];
     int made = 0, rc = PBN_OK;

@@ -94,7 +94,10 @@ __global__ __launch_bounds__(NW * 64) void k_spconv(const ConvArgs a) {
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
     u32x4 pf_sink = {0u, 0u, 0u, 0u};
     if (blockIdx.y == 0 && blockIdx.z == 0) pf_sink = prefetch_next_weights(a, blockIdx.x, gridDim.x, tid, CONV_TPB);
-    const int row0 = xcd_tile(blockIdx.x, gridDim.x) * TM;
+    // the XCD-aware tile map runs over the tiles that HAVE rows (a capacity-sized grid holds more: mapped over the grid, the last
+    // XCDs would get only empty tiles and the first ones all the work -- round 5)
+    const int nt_work = a.n_out_dev ? (n + TM - 1) / TM : (int)gridDim.x;
+    const int row0 = (int)blockIdx.x < nt_work ? xcd_tile(blockIdx.x, nt_work) * TM : n;
 #ifdef PBN_CONV_TIMING
     __shared__ unsigned s_time[NW * 64 * 8];
     const bool timed_ = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0;
@@ -481,7 +484,7 @@ int launch_ring(ConvArgs a, int ngroups, float* workspace, size_t workspace_byte
     a.ksplit = 1;
     a.partial = nullptr;
     a.n_out_pad = tiles * TM;
-    const long long wgs = (long long)tiles * ngroups;
+    const long long wgs = (long long)cdiv(a.n_sel, TM) * ngroups;      // (the split decision follows the rows expected, the grid the capacity)
     // Split-K by a two-term cost model (microseconds, fitted on the bench scene's stride-4..16 levels):
     //   a workgroup's chain of n_groups/ks groups at ~t_group each  +  ks fp32 partial slabs written and read back.
     // The minimum is at ks* = sqrt(n_groups * t_group / slab_cost); more workgroups than ~2 per CU only queue up.
@@ -603,6 +606,7 @@ static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const i
     a.shift = shift; a.residual = residual; a.out = out_feat; a.ld_in = ld_in; a.ld_res = ld_res; a.ld_out = ld_out;
     a.K = n_offsets; a.vpo = vecs_per_offset; a.n_steps = n_steps; a.ntiles_total = cout_padded / 16; a.n_out = n_out;
     a.relu = relu;
+    a.n_sel = (g_rows_hint > 0 && n_out_dev) ? (g_rows_hint < n_out ? g_rows_hint : n_out) : n_out;
     a.ksplit = 1; a.partial = nullptr; a.n_out_pad = 0; a.cg = 1; a.wmajor = 0;
     a.in2 = in2_feat; a.ld_in2 = ld_in2; a.vpo2 = vecs_second; a.n_main = n_main; a.in2_bytes = (unsigned)in2_extent;
     // Next-op weight prefetch, measured round 4 on the bench scene: one scene alone the stride-8 / 16
@@ -634,7 +638,7 @@ static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const i
     }
     float* ws = reinterpret_cast<float*>(workspace);
     if (((uintptr_t)workspace) & 15) ws = nullptr;
-    if (rows_per_wave != 16 && rows_per_wave != 32 && rows_per_wave != 64) rows_per_wave = (n_out > 64) ? 32 : 16;
+    if (rows_per_wave != 16 && rows_per_wave != 32 && rows_per_wave != 64) rows_per_wave = (a.n_sel > 64) ? 32 : 16;
     switch (dtype) {
         case PBN_F32: return launch_t<float>(a, rows_per_wave, ws, workspace_bytes, stream);
         case PBN_BF16: return launch_t<__hip_bfloat16>(a, rows_per_wave, ws, workspace_bytes, stream);
@@ -646,6 +650,7 @@ static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const i
 namespace pbn {
 thread_local NextWeights g_next_weights = {nullptr, 0, 0, 0, 0};
 thread_local RsTableRef g_rs_table = {nullptr, nullptr, 0};
+thread_local int g_rows_hint = 0;
 }
 
 extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,

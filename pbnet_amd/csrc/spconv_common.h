@@ -27,6 +27,7 @@ struct ConvArgs {
     unsigned in_bytes, w_bytes;   // extents of the two buffer resources (< 2 GiB, checked by pbn_spconv_forward)
     int K, vpo, n_steps, ntiles_total;
     int n_out, relu;
+    int n_sel;           // rows the kernel CHOICE is made for (family, tile shape): n_out, or the caller's expectation when n_out is a capacity
     int ksplit;          // >1: this launch writes fp32 partial sums, k_spconv_reduce applies the epilogue
     float* partial;      // [ksplit][n_out_pad][ntiles_total*16]
     int n_out_pad;
@@ -55,6 +56,9 @@ extern thread_local NextWeights g_next_weights;     // set by the executor aroun
 // cleared behind it; a launch whose map is `nbr` uses them
 struct RsTableRef { const int* nbr; const void* table; int n_out; };
 extern thread_local RsTableRef g_rs_table;
+// round 5: expected rows of the NEXT convolution call's output level (capacity-planned forwards: n_out is a capacity 1.25 x larger,
+// and choosing families / tile shapes by it picks slower kernels); 0 = none.  Set by the executor around a call, cleared behind it
+extern thread_local int g_rows_hint;
 
 namespace {
 

@@ -52,12 +52,16 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rs(const ConvArgs a, const in
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, rl = lane & 15;
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
-    // capacity form (n_out is a capacity, the rows that exist are counted on the device): the launch's tiles share the rows that
-    // exist -- a tile height sized by the capacity would leave the last workgroups without work and the others with too much
-    const int tile_rows = a.n_out_dev ? min(tile_rows_launch, (((n + n_tiles - 1) / n_tiles) + 15) & ~15) : tile_rows_launch;
-    const int tile = xcd_tile(blockIdx.x, n_tiles);
+    // capacity form (n_out is a capacity, the rows that exist are counted on the device) WITHOUT a rows hint: the launch's tiles share
+    // the rows that exist -- a tile height sized by the capacity would leave the last workgroups without work and the others with too
+    // much.  With a hint (n_sel < n_out) the tiles were cut for the rows expected and those behind the count simply exit
+    const int tile_rows = (a.n_out_dev && a.n_sel == a.n_out) ? min(tile_rows_launch, (((n + n_tiles - 1) / n_tiles) + 15) & ~15) : tile_rows_launch;
+    // tiles that have rows (the launch may hold more: capacities); the XCD-aware map runs over THOSE, so that every XCD gets the
+    // same share of working tiles (mapped over the launch's tiles, the last XCDs would hold only empty ones)
+    const int n_work = (n + tile_rows - 1) / tile_rows;
+    if ((int)blockIdx.x >= n_work) return;
+    const int tile = xcd_tile(blockIdx.x, n_work);
     const int row0 = tile * tile_rows;
-    if (row0 >= n) return;
     const int live = min(tile_rows, n - row0);
 
     if (tid < 4) s_act[tid] = 0u;
@@ -701,10 +705,11 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rsh(const ConvArgs a, const i
     const int g = lane >> 4, rl = lane & 15;
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
     // capacity form: the launch's tiles share the rows that exist (see k_spconv_rs); the LDS layout stays the launch's
-    const int tile_rows = a.n_out_dev ? min(tile_rows_launch, (((n + n_tiles - 1) / n_tiles) + 15) & ~15) : tile_rows_launch;
-    const int tile = xcd_tile(blockIdx.x, n_tiles);
+    const int tile_rows = (a.n_out_dev && a.n_sel == a.n_out) ? min(tile_rows_launch, (((n + n_tiles - 1) / n_tiles) + 15) & ~15) : tile_rows_launch;
+    const int n_work = (n + tile_rows - 1) / tile_rows;       // tiles that have rows: the XCD-aware map runs over those (see k_spconv_rs)
+    if ((int)blockIdx.x >= n_work) return;
+    const int tile = xcd_tile(blockIdx.x, n_work);
     const int row0 = tile * tile_rows;
-    if (row0 >= n) return;
     const int live = min(tile_rows, n - row0);
     const bool cube = (K == 27 || K == 125) && n_in == a.n_out;     // same-level map: the window is the tile's own rows
     RSH_T0
@@ -996,7 +1001,9 @@ int cu_count() {
 
 // tile height: the level cut into (a multiple of) one tile per CU, rounded up to whole fragments
 struct RsShape { int tile_rows, n_tiles, nf; };
-RsShape rs_shape(int n_out, int force_nf, int force_rows = 0) {
+RsShape rs_shape(int n_sel, int force_nf, int force_rows = 0, int n_out = -1) {
+    // n_sel: the rows the tile height is chosen for; n_out (>= n_sel: a capacity) the rows the tiles must cover
+    if (n_out < 0) n_out = n_sel;
     RsShape s;
     if (force_rows > 0) {                    // tests: an explicit tile height (a multiple of 16, at most 128 rows per fragment count)
         s.tile_rows = ((force_rows + 15) / 16) * 16;
@@ -1010,12 +1017,12 @@ RsShape rs_shape(int n_out, int force_nf, int force_rows = 0) {
     if (force_nf > 0) {
         s.nf = force_nf;
         s.tile_rows = RS_NW * 16 * force_nf;
-        const int rounds = cdiv(cdiv(n_out, s.tile_rows), cus);
-        const int per = cdiv(n_out, cus * (rounds > 0 ? rounds : 1));
+        const int rounds = cdiv(cdiv(n_sel, s.tile_rows), cus);
+        const int per = cdiv(n_sel, cus * (rounds > 0 ? rounds : 1));
         s.tile_rows = min(s.tile_rows, ((per + 15) / 16) * 16);
     } else {
         for (int rounds = 1;; ++rounds) {
-            const int per = cdiv(n_out, cus * rounds);
+            const int per = cdiv(n_sel, cus * rounds);
             s.tile_rows = ((per + 15) / 16) * 16;
             if (s.tile_rows <= RS_NW * 16 * RS_NF_MAX) break;
         }
@@ -1138,11 +1145,11 @@ bool rs_family_wanted(const ConvArgs& a, int dtype) {
     static const int env = getenv("PBN_CONV_RS") ? atoi(getenv("PBN_CONV_RS")) : 1;
     static const int min_rows = getenv("PBN_RS_MIN_ROWS") ? atoi(getenv("PBN_RS_MIN_ROWS")) : 20000;
     static const int min_rows2 = getenv("PBN_RS_MIN_ROWS2") ? atoi(getenv("PBN_RS_MIN_ROWS2")) : 40000;
-    if (!env || dtype == PBN_F32 || a.row_perm || a.K > 32 || a.n_out < min_rows) return false;
+    if (!env || dtype == PBN_F32 || a.row_perm || a.K > 32 || a.n_sel < min_rows) return false;
     const int cg = rs_cg(a);
     if (!cg) return false;
     const int nt = a.ntiles_total;
-    return (nt == 6 && (cg == 3 || cg == 4)) || (nt == 2 && cg == 1 && a.n_out >= min_rows2);
+    return (nt == 6 && (cg == 3 || cg == 4)) || (nt == 2 && cg == 1 && a.n_sel >= min_rows2);
 }
 
 // cfg: 0 = automatic (form and tile height); 1..5 = that many fragments per wave (tests, tuning); + 1000: the staged form (rows in
@@ -1158,14 +1165,14 @@ int launch_rs(const ConvArgs& a, int dtype, int cfg, hipStream_t stream) {
     else if (cfg >= 1000) { staged = 1; cfg -= 1000; }
     if (a.row_perm || a.K > 32 || (a.vpo & 3) || cfg < 0 || cfg > RS_NF_MAX) return PBN_ERR_UNSUPPORTED;
     if (automatic) {
-        const RsShape sh = rs_shape(a.n_out, 0);
+        const RsShape sh = rs_shape(a.n_sel, 0, 0, a.n_out);
         const unsigned esz = dtype == PBN_F32 ? 4u : 2u;
         const bool cube = a.K == 27 && a.ld_in > 0 && (int)(a.in_bytes / ((unsigned)a.ld_in * esz)) == a.n_out;
         const bool gather_ok = !(a.ntiles_total == 6 && cg == 4 && sh.nf == 5);       // (that instantiation spills)
-        staged = (cube && a.rs_table && rs_staged_pays(a.n_out, a.ntiles_total)) || !gather_ok;
+        staged = (cube && a.rs_table && rs_staged_pays(a.n_sel, a.ntiles_total)) || !gather_ok;
     }
     if (staged && a.nbr && (a.ntiles_total == 6 || a.ntiles_total == 2) && (!a.in2 || !(a.vpo2 & 3))) {
-        const RsShape sh = rs_shape(a.n_out, cfg, force_rows);
+        const RsShape sh = rs_shape(a.n_sel, cfg, force_rows, a.n_out);
         int rc = PBN_ERR_UNSUPPORTED;
         switch (dtype) {
             case PBN_BF16: rc = launch_rsh_t<__hip_bfloat16>(a, sh, stream); break;
@@ -1180,7 +1187,7 @@ int launch_rs(const ConvArgs& a, int dtype, int cfg, hipStream_t stream) {
     if (!a.in2 && a.n_steps % cg) return PBN_ERR_UNSUPPORTED;
     ConvArgs b = a;
     b.cg = cg;
-    const RsShape s = rs_shape(a.n_out, cfg, force_rows);
+    const RsShape s = rs_shape(a.n_sel, cfg, force_rows, a.n_out);
     switch (dtype) {
         case PBN_BF16: return launch_rs_t<__hip_bfloat16>(b, s, cg, stream);
         case PBN_F16: return launch_rs_t<__half>(b, s, cg, stream);

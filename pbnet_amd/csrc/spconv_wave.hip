@@ -163,7 +163,11 @@ __global__ __launch_bounds__(KW * 64) void k_spconv_wave(const ConvArgs a) {
     PBN_WSTAMP(0);
     const int n_groups = a.ntiles_total / NT;
     u32x4 pf_sink = prefetch_next_weights(a, blockIdx.x, gridDim.x, tid, TPB);
-    const TileMap tm = map_block(a, (a.n_out + TM - 1) / TM, n_groups);
+    // row tiles that HAVE rows: with a device-side count the grid is sized by a capacity, and mapping the blocks over the grid's
+    // tiles would hand the last XCDs only empty ones (round 5)
+    const int n_rows_now = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
+    if (n_rows_now <= 0) { prefetch_drain(pf_sink); return; }
+    const TileMap tm = map_block(a, (n_rows_now + TM - 1) / TM, n_groups);
     if (!tm.valid) { prefetch_drain(pf_sink); return; }
     const int row0 = tm.row_tile * TM;
     const int tile0 = tm.group * NT;
@@ -554,7 +558,7 @@ int launch_by_cfg(const ConvArgs& a, int cfg, hipStream_t stream) {
 // spreads ONE row tile over 8 waves, so it is the mode of choice whenever row-split tiles alone cannot fill the CUs.
 int pick_cfg(const ConvArgs& a) {
     const int ntt = a.ntiles_total;
-    const long long rows = a.n_out;
+    const long long rows = a.n_sel;
     // stem-like layers (a 16/32-byte input row, K = 125): 32 rows x 32 channels per workgroup measured best at every size
     // (146 k rows: 44.8 us against 68.1 for 64 rows and 72.6 for the workgroup-tile kernel)
     if (a.vpo <= 2 && a.K >= 64 && ntt % 2 == 0) return 1202;
@@ -650,8 +654,8 @@ bool wave_family_wanted(const ConvArgs& a, int dtype) {
     if (fam == 1) return true;
     if (a.vpo <= 8 && a.K >= 64 && !a.row_perm) return true;   // the k = 5 stems: rulebook-bound, no weight reuse to speak of
     const double elems_per_step = 4.0 * (dtype == PBN_F32 ? 4.0 : 8.0);
-    const double dense = (double)a.n_out * a.n_steps * elems_per_step * a.ntiles_total * 16.0;
-    return a.n_out < max_rows && dense <= max_macs;
+    const double dense = (double)a.n_sel * a.n_steps * elems_per_step * a.ntiles_total * 16.0;
+    return a.n_sel < max_rows && dense <= max_macs;
 }
 
 }  // namespace pbn

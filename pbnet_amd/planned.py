@@ -36,6 +36,7 @@ OVF_NAMES = {1: "selected points", 2: "clusters", 4: "local-scene entries", 8: "
 MASK_THD = 0.45
 LOCAL_VOXEL = 0.02
 _DEBUG = os.environ.get("PBN_PLANNED_DEBUG", "0") == "1"
+HINTS = os.environ.get("PBN_PLANNED_HINTS", "1") != "0"      # kernel choice by the rows expected, not by the capacities
 _STOP = os.environ.get("PBN_PLANNED_STOP", "")      # debugging: end the launch sequence after the named stage
 
 
@@ -55,6 +56,9 @@ class Capacities(object):
     def __init__(self, **kw):
         for k in self.FIELDS:
             setattr(self, k, kw[k])
+        # rows EXPECTED per level (the measured ones): the kernels' family / tile choice follows these, the grids the capacities
+        # (round 5: choosing by the 1.25 x capacities picked slower kernels -- pbn_unet_set_rows_hint)
+        self.expect = kw.get("expect") or {"lv1": list(self.lv1), "lv2": list(self.lv2), "lv3": list(self.lv3)}
 
     def padded(self, slack=1.25, quantum=256):
         """The same plan with head room: every data-dependent size x slack, rounded up to a multiple of `quantum`."""
@@ -63,7 +67,7 @@ class Capacities(object):
         return Capacities(n_points=self.n_points, n_voxels=self.n_voxels,
                           lv1=[self.n_voxels] + [up(v) for v in self.lv1[1:]], lv2=[up(v) for v in self.lv2],
                           lv3=[up(v) for v in self.lv3], points=min(self.n_points, up(self.points)),
-                          clusters=up(self.clusters, 64), entries=up(self.entries, 64), rows=up(self.rows))
+                          clusters=up(self.clusters, 64), entries=up(self.entries, 64), rows=up(self.rows), expect=self.expect)
 
     def __repr__(self):
         return "Capacities(%s)" % ", ".join("%s=%r" % (k, getattr(self, k)) for k in self.FIELDS)
@@ -71,8 +75,13 @@ class Capacities(object):
 
 def measure_capacities(model, feat_voxel, xyz_voxel, xyz_original, v2p_index, teacher=None):
     """One size-exact forward that records every data-dependent size (PBNet._last_sizes)."""
-    with torch.no_grad():
-        model(feat_voxel, xyz_voxel, xyz_original, v2p_index, None, 1, "test", teacher=teacher)
+    keep = getattr(model, "planned_cache", False)
+    model.planned_cache = False                 # the size-exact forward, whatever the model's cache holds for these sizes
+    try:
+        with torch.no_grad():
+            model(feat_voxel, xyz_voxel, xyz_original, v2p_index, None, 1, "test", teacher=teacher)
+    finally:
+        model.planned_cache = keep
     s = model._last_sizes
     return Capacities(n_points=int(xyz_original.shape[0]), n_voxels=int(feat_voxel.shape[0]), lv1=list(s["lv1"]),
                       lv2=list(s.get("lv2", [1] * 5)), lv3=list(s.get("lv3", [1] * 5)), points=int(s.get("points", 1)),
@@ -130,7 +139,7 @@ class PlannedForward(object):
                         for lv in (cap.lv1, cap.lv2, cap.lv3)}
 
     # ---- helpers ----------------------------------------------------------------------------------------------------
-    def _unet(self, net, lin, cap_levels, feats, row_bytes):
+    def _unet(self, net, lin, cap_levels, feats, row_bytes, expect=None):
         """Fused U-Net on a lineage: feats are the INPUT rows (before de-duplication); returns the output slab in Z-order
         [cap_levels[0], cout] and flags a level whose row count exceeds its capacity."""
         lib = N.lib()
@@ -154,6 +163,8 @@ class PlannedForward(object):
         # pool of one captured graph to the next and dangle once the first graph is released
         ws = self._splitk_ws
         vp = ctypes.c_void_p
+        if expect is not None and HINTS:
+            lib.pbn_unet_set_rows_hint((ctypes.c_int32 * 5)(*[max(1, min(int(e), int(c))) for e, c in zip(expect, cap_levels)]))
         N.check(lib.pbn_unet_forward_dev(plan["ops"], plan["n_ops"], plan["bufs"], plan["n_bufs"], n_rows,
                                          vp(lin.counts.data_ptr()), vp(padded.data_ptr()), cin_p, k3, k5, down, up,
                                          vp(arena.data_ptr()), nbytes, _DT[dt], vp(ws.data_ptr()), ws.numel(),
@@ -198,7 +209,7 @@ class PlannedForward(object):
         if _STOP == "prepare1":
             return {"counts": counts, "_keep": {"lin1": lin1, "coords1": coords1}}
         feats1 = feat_voxel.contiguous()
-        f = self._unet(m.MEUnet, lin1, cap.lv1, feats1, feats1.shape[1] * es)
+        f = self._unet(m.MEUnet, lin1, cap.lv1, feats1, feats1.shape[1] * es, cap.expect["lv1"])
         _dbg("backbone done", counts)
         if _STOP == "backbone":
             return {"counts": counts, "_keep": {k: v for k, v in locals().items() if torch.is_tensor(v) or isinstance(v, _Lineage)}}
@@ -263,7 +274,7 @@ class PlannedForward(object):
             return {"counts": counts, "_keep": {k: v for k, v in locals().items() if torch.is_tensor(v) or isinstance(v, _Lineage)}}
         # ---- mask branch (PBNet.py:236-252) ----
         lin2 = _Lineage(coords2, r_cap, cnt(CNT.ROWS), dev)
-        f2 = self._unet(m.D_Unet, lin2, cap.lv2, feat2, ld2 * es)
+        f2 = self._unet(m.D_Unet, lin2, cap.lv2, feat2, ld2 * es, cap.expect["lv2"])
         mask_score = self._mlp(m.linear_binary, f2, lin2.inverse, lin2.inv_perm, r_cap, cnt(CNT.ROWS))      # [r_cap, 1]
 
         _dbg("mask branch done", counts)
@@ -294,7 +305,7 @@ class PlannedForward(object):
             return {"counts": counts, "_keep": {k: v for k, v in locals().items() if torch.is_tensor(v) or isinstance(v, _Lineage)}}
         # ---- score branch (PBNet.py:255-279) ----
         lin3 = _Lineage(coords3, r_cap, cnt(CNT.PROPOSAL_ROWS), dev)
-        f3 = self._unet(m.score_Unet, lin3, cap.lv3, feat3, c_in * es)
+        f3 = self._unet(m.score_Unet, lin3, cap.lv3, feat3, c_in * es, cap.expect["lv3"])
         n3 = int(cap.lv3[0])
         iou_feat = self._mlp(m.linear_IOU_feat, f3, lin3.inv_perm, None, n3, lin3.counts.data_ptr())     # external row order
         seg_start = torch.empty(c_cap + 1, **i32)
