@@ -128,7 +128,6 @@ class GradientReducer(object):
         if b["flat"] is None or b["flat"].device != like.device:
             b["flat"] = torch.empty(b["numel"], dtype=self.comm_dtype, device=like.device)
             b["views"] = [b["flat"][o:o + p.numel()].view_as(p) for o, p in zip(b["offsets"], b["params"])]
-            b["typed"] = {}
         return b["flat"]
 
     def _pack(self, b, like):
