@@ -38,6 +38,7 @@ Also on the JSON line:
   phases_s     -- wall clock of the phases of this run (build, warm-up, timed blocks, probes, TTA leg, CPU baseline).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -57,7 +58,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_SUMMARIES = ("r05_c_pmc_summary.json", "r05_b_pmc_summary.json", "r05_a_pmc_summary.json", "r04_d_pmc_summary.json", "r04_c_pmc_summary.json", "r04_b_pmc_summary.json", "r04_a_pmc_summary.json", "r03_c_pmc_summary.json", "r03_b_pmc_summary.json", "r03_a_pmc_summary.json", "r02_b_pmc_summary.json", "r02_a_pmc_summary.json", "r01_pmc_summary.json")   # newest first
+PMC_SUMMARIES = ("r05_d_pmc_summary.json", "r05_c_pmc_summary.json", "r05_b_pmc_summary.json", "r05_a_pmc_summary.json", "r04_d_pmc_summary.json", "r04_c_pmc_summary.json", "r04_b_pmc_summary.json", "r04_a_pmc_summary.json", "r03_c_pmc_summary.json", "r03_b_pmc_summary.json", "r03_a_pmc_summary.json", "r02_b_pmc_summary.json", "r02_a_pmc_summary.json", "r01_pmc_summary.json")   # newest first
 
 
 WORKLOADS = {
@@ -172,65 +173,36 @@ def inflight_streams(device, n):
     key = (str(device), n)
     if key not in _STREAMS:
         _STREAMS[key] = [torch.cuda.Stream(device) for _ in range(n)]
+        for st in _STREAMS[key]:        # first USE is what binds a stream to a hardware queue: do it now, in this order, before
+            with torch.cuda.stream(st):  # anything else of the process (graph capture side streams, ...) takes queues in between
+                torch.zeros(16, device=device).add_(1)
+        torch.cuda.synchronize(device)
     return _STREAMS[key]
 
 
 def planned_leg(model, b, t, dtype, inflight, device, steps, graph):
     """The sync-free forward (pbnet_amd/planned.py: every data-dependent size stays on the device) on `inflight` streams, eager
-    launch sequence or HIP-graph replay: scenes/s, and one scene alone in ms.  The difference to the headline (the eager
+    launch sequence or HIP-graph replay: scenes/s, and one scene alone in ms.  The difference to the headline (the size-exact
     forward with its three read-backs) is what the host costs."""
-    from pbnet_amd import planned
-    args = (b["feat_voxel"].to(dtype), b["xyz_voxel"], b["xyz_original"], b["v2p_index"])
-    cap = planned.measure_capacities(model, *args, teacher=t).padded(1.25)
-    streams = inflight_streams(device, inflight)
-    pfs = []
-    for st in streams:
-        with torch.cuda.stream(st):
-            pf = planned.PlannedForward(model, cap, dtype=dtype)
-            pf(*args, teacher=t)
-            if graph:
-                pf.capture(*args, teacher=t)
-            pfs.append(pf)
-        torch.cuda.synchronize()
-    errors = []
-
-    def step(i):
-        return pfs[i].finish(pfs[i].replay()) if graph else pfs[i](*args, teacher=t)
-
-    def run(n, m):
-        def worker(i):
-            try:
-                torch.cuda.set_device(device)
-                with torch.cuda.stream(streams[i]):
-                    for _ in range(i, n, m):
-                        step(i)
-                    streams[i].synchronize()
-            except BaseException as e:
-                errors.append(e)
-        th = [threading.Thread(target=worker, args=(i,)) for i in range(m)]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        if errors:
-            raise errors[0]
-    run(2 * inflight, inflight)
+    r = Runner(model, b, t, inflight, device, mode="graph" if graph else "planned", dtype=dtype)
+    r.run(2 * inflight)
     bl = []
     for _ in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run(steps, inflight)
+        r.run(steps)
         torch.cuda.synchronize()
         bl.append(time.perf_counter() - t0)
     e = float(np.median(bl))
-    run(3, 1)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    run(8, 1)
-    torch.cuda.synchronize()
-    alone = (time.perf_counter() - t1) / 8 * 1e3
-    out = step(0)
-    torch.cuda.synchronize()
+    with torch.cuda.stream(r.streams[0]) if r.streams[0] is not None else contextlib.nullcontext():
+        r.run(3, threads=1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r.run(8, threads=1)
+        torch.cuda.synchronize()
+        alone = (time.perf_counter() - t1) / 8 * 1e3
+        out = r.step(0)
+        torch.cuda.synchronize()
     finite = bool(torch.isfinite(out["clt_scores"].float()).all()) if out["clt_scores"].numel() else True
     return {"value": round(steps / e, 3), "unit": "scenes/s", "ms_per_step": round(e / steps * 1e3, 3),
             "scenes_in_flight": inflight, "one_scene_in_flight_ms_per_scene": round(alone, 3),
@@ -363,12 +335,15 @@ def pmc_traffic(args):
 def gpu_active(args):
     """gpu_active_frac: union of kernel intervals / wall from the newest committed kernel-trace summary of
     this command line (scripts/profile_round.sh -> profiles/<tag>_bench_concurrency.json for the in-flight mode,
-    <tag>_inflight1_concurrency.json for one scene alone).  A trace cannot be taken from inside the process."""
+    <tag>_inflight1_concurrency.json for one scene alone, <tag>_planned_concurrency.json / <tag>_graph_concurrency.json for
+    `--forward-mode planned / graph` with four scenes in flight).  A trace cannot be taken from inside the process."""
     if args.copies != 1 or args.dtype != "bf16" or args.workload != "c2":
         return None
     out = {}
-    for tag in ("r05_c", "r05_b", "r05_a"):
-        for key, name in (("in_flight", "%s_bench_concurrency.json" % tag), ("one_scene", "%s_inflight1_concurrency.json" % tag)):
+    for tag in ("r05_d", "r05_c", "r05_b", "r05_a"):
+        for key, name in (("in_flight", "%s_bench_concurrency.json" % tag), ("one_scene", "%s_inflight1_concurrency.json" % tag),
+                          ("in_flight_planned_eager", "%s_planned_concurrency.json" % tag),
+                          ("in_flight_graph", "%s_graph_concurrency.json" % tag)):
             if key in out:
                 continue
             try:
@@ -416,17 +391,43 @@ def grouped_points(raw):
 
 
 class Runner(object):
-    """K steps taken round-robin by `inflight` host threads, one HIP stream each (inflight 1: a plain loop)."""
+    """K steps taken round-robin by `inflight` host threads, one HIP stream each (inflight 1: a plain loop).
+    mode "size-exact": `model(...)` (the headline); "planned" / "graph": the sync-free forward of pbnet_amd/planned.py on
+    capacities of 1.25 x this scene's measured sizes, issued as eager launches / replayed from one HIP graph per stream."""
 
-    def __init__(self, model, b, t, inflight, device):
-        self.model, self.b, self.t, self.inflight, self.device = model, b, t, inflight, device
+    def __init__(self, model, b, t, inflight, device, mode="size-exact", dtype=None):
+        self.model, self.b, self.t, self.inflight, self.device, self.mode = model, b, t, inflight, device, mode
         self.streams = inflight_streams(device, inflight) if inflight > 1 else [None]
         self.last = [None] * len(self.streams)
+        self.pfs = None
+        if mode != "size-exact":
+            from pbnet_amd import planned
+            dtype = dtype or b["feat_voxel"].dtype
+            self.args = (b["feat_voxel"].to(dtype), b["xyz_voxel"], b["xyz_original"], b["v2p_index"])
+            cap = planned.measure_capacities(model, *self.args, teacher=t).padded(1.25)
+            self.pfs = []
+            for st in self.streams:
+                with torch.cuda.stream(st if st is not None else torch.cuda.current_stream(device)):
+                    pf = planned.PlannedForward(model, cap, dtype=dtype)
+                    pf(*self.args, teacher=t)
+                    if mode == "graph":
+                        pf.capture(*self.args, teacher=t)
+                    self.pfs.append(pf)
+                torch.cuda.synchronize()
 
-    def run(self, n):
-        if self.inflight == 1:
+    def step(self, i):
+        if self.pfs is None:
+            return one_step(self.model, self.b, self.t)
+        pf = self.pfs[i]
+        return pf.finish(pf.replay()) if self.mode == "graph" else pf(*self.args, teacher=self.t)
+
+    def run(self, n, threads=None):
+        m = self.inflight if threads is None else threads
+        if m <= 1:
             for _ in range(n):
-                self.last[0] = one_step(self.model, self.b, self.t)
+                self.last[0] = self.step(0)
+            if self.streams[0] is not None:
+                torch.cuda.synchronize()
             return
         errors = []
 
@@ -434,12 +435,12 @@ class Runner(object):
             try:
                 torch.cuda.set_device(self.device)
                 with torch.cuda.stream(self.streams[i]):
-                    for _ in range(i, n, self.inflight):
-                        self.last[i] = one_step(self.model, self.b, self.t)
+                    for _ in range(i, n, m):
+                        self.last[i] = self.step(i)
                     self.streams[i].synchronize()
             except BaseException as e:      # surfaced below: a failed worker must fail the bench
                 errors.append(e)
-        threads = [threading.Thread(target=worker, args=(i,)) for i in range(self.inflight)]
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(m)]
         for th in threads:
             th.start()
         for th in threads:
@@ -589,6 +590,9 @@ def main():
                     help="sys.setswitchinterval for the in-flight host threads (0 = Python's default 5 ms)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="scenes in flight per GPU (one host thread + HIP stream each); 1 = the reference's loop")
+    ap.add_argument("--forward-mode", default="size-exact", choices=["size-exact", "planned", "graph"],
+                    help="what a step runs: model(...) (the headline, default); the sync-free forward of pbnet_amd/planned.py as "
+                         "eager launches; the same replayed from one HIP graph per stream (for profiles of those modes: use with --no-extras)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
                     help="c2 = BASELINE configs[1] (default, the metric); c4 = configs[3], the dense 1 cm stress scene")
     ap.add_argument("--dry-run", action="store_true",
@@ -635,9 +639,9 @@ def main():
 
     if args.switch_interval > 0:
         sys.setswitchinterval(args.switch_interval)
-    runner = Runner(model, b, t, args.inflight, device)
     one_step(model, b, t)                   # fills the weight / threshold caches once, on one thread
     torch.cuda.synchronize()
+    runner = Runner(model, b, t, args.inflight, device, mode=args.forward_mode)
     runner.run(args.inflight)               # every stream allocates its scratch and allocator pools once
     phase("first_steps")
     runner.run(args.warmup)
@@ -704,7 +708,10 @@ def main():
 
         # the launches are timed in the mode the timed region ran in: with several scenes in flight a launch shares the
         # CUs with the other streams' kernels, so its own duration grows while the whole-job rate rises
-        leg = probe_leg(runner.run, n_probe)
+        # (a planned / graph run is probed through the size-exact launches of the same scene: the per-op events live in the
+        # size-exact executor entry; the planned forward runs the same kernels over capacity-sized buffers)
+        probe_runner = runner if args.forward_mode == "size-exact" else Runner(model, b, t, args.inflight, device)
+        leg = probe_leg(probe_runner.run, n_probe)
         traffic, traffic_src = pmc_traffic(args)
         roof = {"bound": "hbm", "achieved": leg.pop("achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": leg.pop("frac"), "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_spconv*"}
@@ -876,7 +883,7 @@ def main():
                                       info["n_points"] // args.copies, info["n_voxels"] // args.copies,
                                       WORKLOADS[args.workload]["voxel"] * 100, args.copies,
                                       "y" if args.copies == 1 else "ies"),
-                       "forward_path": "size-exact (the opt-in capacity cache is measured as legs.planned.cached_forward)",
+                       "forward_path": "size-exact (the opt-in capacity cache is measured as legs.planned.cached_forward)" if args.forward_mode == "size-exact" else args.forward_mode + " (pbnet_amd/planned.py, capacities 1.25 x this scene's sizes; NOT the headline configuration)",
                        "points_per_step": info["n_points"], "voxels_per_step": info["n_voxels"],
                        "proposals_per_step": n_prop, "scenes_in_flight_per_gpu": args.inflight,
                        "one_scene_in_flight_ms_per_scene": None if single_ms is None else round(single_ms, 3),

@@ -3,6 +3,7 @@
 #   <tag>_bench.json                   the default bench.py line
 #   <tag>_bench_kernel_stats.csv       rocprofv3 --kernel-trace --stats of the same command (no CPU baseline)
 #   <tag>_inflight1_kernel_stats.csv   the same with one scene in flight
+#   <tag>_{bench,inflight1,planned,graph}_concurrency.json   union of kernel intervals / wall of those traces (+ --forward-mode planned / graph)
 #   <tag>_pmc_summary.json             HBM traffic per kernel family: two --pmc passes (FETCH_SIZE, WRITE_SIZE), own runs
 #   <tag>_sq_conv_summary.json         SQ counters (MFMA busy, waits) of the convolution kernels, own pass
 #   <tag>_train_step.json / <tag>_train_kernel_stats.csv   scripts/train_step.py (configs[2] on one rank) and its kernel table
@@ -21,6 +22,13 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- py
 PBN_TRACE_JSON=$O/${TAG}_bench_concurrency.json python scripts/analyze_trace.py $(find $O/kt -name "*kernel_trace.csv" | head -1) > $O/${TAG}_bench_concurrency.txt 2>&1; head -3 $O/${TAG}_bench_concurrency.txt
 PBN_TRACE_JSON=$O/${TAG}_inflight1_concurrency.json python scripts/analyze_trace.py $(find $O/kt1 -name "*kernel_trace.csv" | head -1) > $O/${TAG}_inflight1_concurrency.txt 2>&1; head -3 $O/${TAG}_inflight1_concurrency.txt
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv
+# the sync-free forward as eager launches and from HIP graphs, four in flight: how much of the wall has a kernel running
+for m in planned graph; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$m -- python bench.py --no-extras --forward-mode $m --min-seconds 0.5 > $O/kt_$m.log 2>&1
+  PBN_TRACE_JSON=$O/${TAG}_${m}_concurrency.json python scripts/analyze_trace.py $(find $O/kt_$m -name "*kernel_trace.csv" | head -1) > $O/${TAG}_${m}_concurrency.txt 2>&1; head -3 $O/${TAG}_${m}_concurrency.txt
+  grep "^{" $O/kt_$m.log | tail -1 | cut -c1-120
+  rm -rf $O/kt_$m
+done
 cp $(find $O/kt1 -name "*kernel_stats.csv" | head -1) $O/${TAG}_inflight1_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pmc_$c
