@@ -17,14 +17,15 @@ cd $R
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 timeout 600 python bench.py 2> $O/bench.err | grep "^{" > $O/${TAG}_bench.json; tail -1 $O/${TAG}_bench.json | cut -c1-200
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --no-extras --min-seconds 0.5 > $O/kt.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-extras --inflight 1 --min-seconds 0.5 > $O/kt1.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --no-extras --min-seconds 3 > $O/kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-extras --inflight 1 --min-seconds 3 > $O/kt1.log 2>&1
 PBN_TRACE_JSON=$O/${TAG}_bench_concurrency.json python scripts/analyze_trace.py $(find $O/kt -name "*kernel_trace.csv" | head -1) > $O/${TAG}_bench_concurrency.txt 2>&1; head -3 $O/${TAG}_bench_concurrency.txt
 PBN_TRACE_JSON=$O/${TAG}_inflight1_concurrency.json python scripts/analyze_trace.py $(find $O/kt1 -name "*kernel_trace.csv" | head -1) > $O/${TAG}_inflight1_concurrency.txt 2>&1; head -3 $O/${TAG}_inflight1_concurrency.txt
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv
+# (3 s of timed blocks: analyze_trace.py's window, 35-80 % of the trace, then lies inside the timed region)
 # the sync-free forward as eager launches and from HIP graphs, four in flight: how much of the wall has a kernel running
 for m in planned graph; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$m -- python bench.py --no-extras --forward-mode $m --min-seconds 0.5 > $O/kt_$m.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$m -- python bench.py --no-extras --forward-mode $m --min-seconds 3 > $O/kt_$m.log 2>&1
   PBN_TRACE_JSON=$O/${TAG}_${m}_concurrency.json python scripts/analyze_trace.py $(find $O/kt_$m -name "*kernel_trace.csv" | head -1) > $O/${TAG}_${m}_concurrency.txt 2>&1; head -3 $O/${TAG}_${m}_concurrency.txt
   grep "^{" $O/kt_$m.log | tail -1 | cut -c1-120
   rm -rf $O/kt_$m
