@@ -41,6 +41,13 @@ TRAIN_FUSED_GLUE = os.environ.get("PBNET_TRAIN_FUSED_GLUE", "1") == "1"
 # same input every time.  An exceeded capacity or any failure of the planned path falls back to the size-exact forward.
 PLANNED_CACHE = os.environ.get("PBNET_PLANNED_CACHE", "0") == "1"
 PLANNED_SLACK = float(os.environ.get("PBNET_PLANNED_SLACK", "1.25"))
+# Round 5: the size-exact inference forward takes its class gate, the selection, the grouping AND the local-scene plan on the
+# device (csrc/plan.hip: pbn_class_gate / pbn_local_plan, the entries the planned forward uses) over buffers bounded by the
+# number of points, and reads the four sizes back ONCE where it used to read the class table, then the cluster table, and run
+# the per-(class, batch) cdist / topk plan on the host (PBNet.py:151-234).  Same integers (the device plan is the one
+# tests/test_planned_gpu.py pins to the host plan); more than FRONT_CLUSTER_CAP clusters -> the host path.  "0": the host path.
+DEVICE_FRONT = os.environ.get("PBNET_DEVICE_FRONT", "1") == "1"
+FRONT_CLUSTER_CAP = 1024
 
 
 def _mlp(cin, mid, cout, sigmoid=False):
@@ -283,163 +290,180 @@ class PBNet(nn.Module):
         nb = self.cluster_batch
         n_cls = int(self.sem_num)
 
-        # (a6) per-class selection, all classes at once; host learns the [class, batch] population table
-        _sec = section("a6_select"); _sec.__enter__()
-        if fused:
-            table = s1["table"]
-        else:
-            batch_head_p = s1["batch_head_p"].long()
-            table = torch.bincount(sem_pred_p * nb + batch_head_p, minlength=n_cls * nb)[:n_cls * nb].view(n_cls, nb)
-        mark("a6:before table sync")
-        tab = table.cpu().numpy()                                                 # sync 1
-        mark("a6:table on host")
-        assert int(tab.sum()) == sem_pred_p.shape[0], "batch index outside [0, cluster_batch)"  # PBNet.py:286
-        per_class = tab.sum(1).tolist()
-        thr05, thr02 = self._class_thresholds()
-        classes = [c for c in range(2, n_cls) if not (float(per_class[c]) < thr05[c])]          # PBNet.py:157
-        if not classes:
-            return self._empty_stage(dev, task)
-        m = sum(per_class[c] for c in classes)
-        seg_len_h = tab[classes].reshape(-1).astype(np.int32)                    # segments = (class, batch) in order
-        if fused:
-            # stable class-major selection + the grouping inputs in one launch (positions from the class totals);
-            # class_base and the segment lengths travel in ONE host->device copy
-            class_base = np.full(n_cls, -1, dtype=np.int32)
-            run = 0
-            for c in classes:
-                class_base[c] = run
-                run += per_class[c]
-            up = torch.from_numpy(np.concatenate([class_base, seg_len_h])).to(dev)
-            seg_len = up[n_cls:]
-            with torch.no_grad():
-                ins_ind, ins_orig, ins_offseted, ins_sem = stage_ops.select_points(
-                    sem_pred_p, up[:n_cls], s1["block_hist"], xyz_original, offset_pred_p.detach(), m)
-        else:
-            keep = torch.zeros(n_cls, dtype=torch.bool)
-            keep[classes] = True
-            key = torch.where(keep.to(dev)[sem_pred_p], sem_pred_p, torch.full_like(sem_pred_p, n_cls))
-            order = torch.sort(key, stable=True)[1]
-            ins_ind = order[:m]                                   # class-major, ascending point index inside a class
-            ins_orig = xyz_original[ins_ind]
-            ins_offseted = ins_orig + offset_pred_p[ins_ind].float()                 # PBNet.py:165 (fp32 add)
-            ins_sem = sem_pred_p[ins_ind].to(torch.int32)
-            seg_len = torch.from_numpy(seg_len_h).to(dev)
-        _sec.__exit__(None, None, None)
-
-        if fused and not train_glue:
-            self._last_sizes["points"] = int(m)
-        mark("a7:select queued")
-        with section("a7_16_grouping"):
-            res = pbnet_ops.cluster_device(ins_offseted, ins_orig, ins_sem, seg_len, self.radius, self.min_pts)
-            mark("a7:grouping queued")
-            # one read-back for the cluster table AND the first HEAD_CLUSTERS centres / member offsets (a scene has tens
-            # of clusters; a second read-back follows only when there are more)
-            n_seg = int(res.cluster_num.shape[0])
-            hc = min(HEAD_CLUSTERS, int(res.member_start.shape[0]) - 1)
-            head = torch.cat([res.n_clusters, res.cluster_num, res.member_start[:hc + 1],
-                              res.centers[:3 * hc].view(torch.int32)]).cpu().numpy()   # sync 2
-            mark("a7:grouping done")
-            n_clt = int(head[0])
-        if n_clt < 0:
-            raise RuntimeError("grouping rejected its input (class id outside [2,19])")
-        if n_clt == 0:
-            return self._empty_stage(dev, task)
-        _sec = section("a17_plan"); _sec.__enter__()
-        cluster_num = head[1:1 + n_seg].reshape(len(classes), nb).tolist()
-        if n_clt <= hc:
-            member_start = head[1 + n_seg:1 + n_seg + n_clt + 1]
-            centers = torch.from_numpy(head[2 + n_seg + hc:2 + n_seg + hc + 3 * n_clt].view(np.float32).copy()).view(n_clt, 3)
-        else:
-            packed = torch.cat([res.centers[:3 * n_clt], res.member_start[:n_clt + 1].view(torch.float32)]).cpu()  # sync 3
-            centers = packed[:3 * n_clt].view(n_clt, 3)
-            member_start = packed[3 * n_clt:].view(torch.int32).numpy()
-        mark("a17:centres on host")
-        sizes = (member_start[1:] - member_start[:-1])
-        sizes_l = sizes.tolist()
-        labels_h = None
-        if task != "test":
-            labels_h = ins_label[ins_ind[res.member_idx[:int(member_start[-1])].long()]].cpu()
-
-        # (a17) host plan over clusters: which clusters make up each local scene, and with which weight
-        ent_cluster, ent_weight, scene_len, scene_gt = [], [], [], []
-        k_max = self._k_max_list()
-        g = 0                                                   # running global cluster id (class-major, batch, seed)
-        for ci, cls in enumerate(classes):
-            for b in range(nb):
-                c_b = cluster_num[ci][b]
-                if c_b == 0:
-                    continue
-                para_k = min(c_b - 1, k_max[cls])
-                if para_k > 0:
-                    peak_v = [0.5 * ((para_k + 1) - p_i) / (para_k + 1) for p_i in range(para_k + 1)]
-                    ctr = centers[g:g + c_b]
-                    knn_idx = torch.cdist(ctr, ctr).topk(k=c_b, dim=1, largest=False)[1].tolist()
-                big = thr02[cls]
-                for c_i in range(c_b):
-                    gid = g + c_i
-                    gt = None
-                    if task != "test":
-                        gt = int(torch.mode(labels_h[int(member_start[gid]):int(member_start[gid + 1])])[0])
-                        if gt == -100:
-                            continue
-                    ents, wts = [gid], [1.0]
-                    if float(sizes_l[gid]) > big and para_k > 0:                  # PBNet.py:199
-                        row = knn_idx[c_i]
-                        for k_i in range(para_k):
-                            ents.append(g + row[k_i + 1])
-                            wts.append(peak_v[k_i])
-                    ent_cluster += ents
-                    ent_weight += wts
-                    scene_len.append(len(ents))
-                    scene_gt.append(gt)
-                g += c_b
-        if not scene_len:
-            return self._empty_stage(dev, task)
-
-        _sec.__exit__(None, None, None)
-        mark("a17:plan done")
-        # device gathers over points: rows of every local scene, in the reference's order
-        _sec = section("a17_gather"); _sec.__enter__()
-        ent_np = np.asarray(ent_cluster, dtype=np.int64)
-        if not torch.is_grad_enabled() or train_glue:
-            # inference: ONE launch (pbn_local_scene_rows) driven by one packed host->device copy of the entry table
-            n_ent = len(ent_cluster)
-            row_start = np.zeros(n_ent + 1, dtype=np.int32)
-            np.cumsum(sizes[ent_np], out=row_start[1:])
-            n_rows = int(row_start[-1])
-            ent_scene = np.repeat(np.arange(len(scene_len), dtype=np.int32), scene_len)
-            packed = torch.from_numpy(np.concatenate([row_start, member_start[:-1][ent_np].astype(np.int32), ent_scene,
-                                                      np.asarray(ent_weight, dtype=np.float32).view(np.int32)])).to(dev)
-            with torch.no_grad():
+        # inference: gate, selection, grouping and local-scene plan on the device, ONE read-back (see DEVICE_FRONT)
+        front = None
+        if DEVICE_FRONT and fused and not train_glue and task == "test" and ins_label is None and xyz_original.is_contiguous():
+            front = self._device_front(s1, xyz_original, nb, n_cls)
+            if isinstance(front, str):
+                return self._empty_stage(dev, task)
+        if front is not None:
+            ins_ind, res, packed, n_ent, n_rows, n_clt, m = front
+            n_scenes = n_clt                                    # test mode: every cluster heads one local scene (PBNet.py:182-234)
+            with section("a17_gather"), torch.no_grad():
                 point_idx, row_scene, coords, feat = stage_ops.local_scene_rows(
                     packed, n_ent, n_rows, res.member_idx, ins_ind, xyz_original, LOCAL_VOXEL, point_feat_p.detach(),
-                    sem_sfp.detach(), None if (fused and not train_glue) else sem_pred_p)
-            if train_glue:
-                # the same rows with their gradients: features and own-class scores gathered by torch, the entry weight (a
-                # constant) taken from the fused launch's last column                                  PBNet.py:162-163,194,230
-                row_sem_sf = sem_sfp[point_idx, sem_pred_p[point_idx]]
-                feat = torch.cat([point_feat_p[point_idx], row_sem_sf.view(-1, 1).to(point_feat_p.dtype), feat[:, -1:]], 1)
-            elif fused:
-                self._last_sizes.update(clusters=int(n_clt), entries=int(n_ent), rows=int(n_rows))
+                    sem_sfp.detach(), None)
+            self._last_sizes.update(points=int(m), clusters=int(n_clt), entries=int(n_ent), rows=int(n_rows))
+            _sec = section("a17_plan"); _sec.__enter__()         # (the host plan of the other branch: nothing to do here)
         else:
-            ent_cluster_t = torch.from_numpy(ent_np)
-            ent_rows = torch.from_numpy(sizes.astype(np.int64))[ent_cluster_t]
-            member_start = torch.from_numpy(member_start)
-            ent_scene = torch.repeat_interleave(torch.arange(len(scene_len)), torch.tensor(scene_len))
-            d = lambda t: t.to(dev)
-            row_ent = torch.repeat_interleave(torch.arange(len(ent_cluster), device=dev), d(ent_rows))
-            ent_first = d(torch.cumsum(ent_rows, 0) - ent_rows)
-            pos_in_ent = torch.arange(row_ent.shape[0], device=dev) - ent_first[row_ent]
-            member_pos = d(member_start[:-1][ent_cluster_t])[row_ent] + pos_in_ent
-            local_idx = res.member_idx[member_pos].long()                            # index into the grouped array
-            point_idx = ins_ind[local_idx]                                           # index into the scene's points
-            row_scene = d(ent_scene)[row_ent]
-            row_weight = d(torch.tensor(ent_weight, dtype=torch.float32))[row_ent]
-            row_sem_sf = sem_sfp[point_idx, sem_pred_p[point_idx]]                    # PBNet.py:162-163: own-class score
-            feat = torch.cat([point_feat_p[point_idx], row_sem_sf.view(-1, 1).to(point_feat_p.dtype),
-                              row_weight.view(-1, 1).to(point_feat_p.dtype)], 1)     # [R, 34]  PBNet.py:194,230
-            coords = torch.cat([row_scene.view(-1, 1).to(torch.int32),
-                                torch.floor(xyz_original[point_idx] / LOCAL_VOXEL).to(torch.int32)], 1)
+            # (a6) per-class selection, all classes at once; host learns the [class, batch] population table
+            _sec = section("a6_select"); _sec.__enter__()
+            if fused:
+                table = s1["table"]
+            else:
+                batch_head_p = s1["batch_head_p"].long()
+                table = torch.bincount(sem_pred_p * nb + batch_head_p, minlength=n_cls * nb)[:n_cls * nb].view(n_cls, nb)
+            mark("a6:before table sync")
+            tab = table.cpu().numpy()                                                 # sync 1
+            mark("a6:table on host")
+            assert int(tab.sum()) == sem_pred_p.shape[0], "batch index outside [0, cluster_batch)"  # PBNet.py:286
+            per_class = tab.sum(1).tolist()
+            thr05, thr02 = self._class_thresholds()
+            classes = [c for c in range(2, n_cls) if not (float(per_class[c]) < thr05[c])]          # PBNet.py:157
+            if not classes:
+                return self._empty_stage(dev, task)
+            m = sum(per_class[c] for c in classes)
+            seg_len_h = tab[classes].reshape(-1).astype(np.int32)                    # segments = (class, batch) in order
+            if fused:
+                # stable class-major selection + the grouping inputs in one launch (positions from the class totals);
+                # class_base and the segment lengths travel in ONE host->device copy
+                class_base = np.full(n_cls, -1, dtype=np.int32)
+                run = 0
+                for c in classes:
+                    class_base[c] = run
+                    run += per_class[c]
+                up = torch.from_numpy(np.concatenate([class_base, seg_len_h])).to(dev)
+                seg_len = up[n_cls:]
+                with torch.no_grad():
+                    ins_ind, ins_orig, ins_offseted, ins_sem = stage_ops.select_points(
+                        sem_pred_p, up[:n_cls], s1["block_hist"], xyz_original, offset_pred_p.detach(), m)
+            else:
+                keep = torch.zeros(n_cls, dtype=torch.bool)
+                keep[classes] = True
+                key = torch.where(keep.to(dev)[sem_pred_p], sem_pred_p, torch.full_like(sem_pred_p, n_cls))
+                order = torch.sort(key, stable=True)[1]
+                ins_ind = order[:m]                                   # class-major, ascending point index inside a class
+                ins_orig = xyz_original[ins_ind]
+                ins_offseted = ins_orig + offset_pred_p[ins_ind].float()                 # PBNet.py:165 (fp32 add)
+                ins_sem = sem_pred_p[ins_ind].to(torch.int32)
+                seg_len = torch.from_numpy(seg_len_h).to(dev)
+            _sec.__exit__(None, None, None)
+
+            if fused and not train_glue:
+                self._last_sizes["points"] = int(m)
+            mark("a7:select queued")
+            with section("a7_16_grouping"):
+                res = pbnet_ops.cluster_device(ins_offseted, ins_orig, ins_sem, seg_len, self.radius, self.min_pts)
+                mark("a7:grouping queued")
+                # one read-back for the cluster table AND the first HEAD_CLUSTERS centres / member offsets (a scene has tens
+                # of clusters; a second read-back follows only when there are more)
+                n_seg = int(res.cluster_num.shape[0])
+                hc = min(HEAD_CLUSTERS, int(res.member_start.shape[0]) - 1)
+                head = torch.cat([res.n_clusters, res.cluster_num, res.member_start[:hc + 1],
+                                  res.centers[:3 * hc].view(torch.int32)]).cpu().numpy()   # sync 2
+                mark("a7:grouping done")
+                n_clt = int(head[0])
+            if n_clt < 0:
+                raise RuntimeError("grouping rejected its input (class id outside [2,19])")
+            if n_clt == 0:
+                return self._empty_stage(dev, task)
+            _sec = section("a17_plan"); _sec.__enter__()
+            cluster_num = head[1:1 + n_seg].reshape(len(classes), nb).tolist()
+            if n_clt <= hc:
+                member_start = head[1 + n_seg:1 + n_seg + n_clt + 1]
+                centers = torch.from_numpy(head[2 + n_seg + hc:2 + n_seg + hc + 3 * n_clt].view(np.float32).copy()).view(n_clt, 3)
+            else:
+                packed = torch.cat([res.centers[:3 * n_clt], res.member_start[:n_clt + 1].view(torch.float32)]).cpu()  # sync 3
+                centers = packed[:3 * n_clt].view(n_clt, 3)
+                member_start = packed[3 * n_clt:].view(torch.int32).numpy()
+            mark("a17:centres on host")
+            sizes = (member_start[1:] - member_start[:-1])
+            sizes_l = sizes.tolist()
+            labels_h = None
+            if task != "test":
+                labels_h = ins_label[ins_ind[res.member_idx[:int(member_start[-1])].long()]].cpu()
+
+            # (a17) host plan over clusters: which clusters make up each local scene, and with which weight
+            ent_cluster, ent_weight, scene_len, scene_gt = [], [], [], []
+            k_max = self._k_max_list()
+            g = 0                                                   # running global cluster id (class-major, batch, seed)
+            for ci, cls in enumerate(classes):
+                for b in range(nb):
+                    c_b = cluster_num[ci][b]
+                    if c_b == 0:
+                        continue
+                    para_k = min(c_b - 1, k_max[cls])
+                    if para_k > 0:
+                        peak_v = [0.5 * ((para_k + 1) - p_i) / (para_k + 1) for p_i in range(para_k + 1)]
+                        ctr = centers[g:g + c_b]
+                        knn_idx = torch.cdist(ctr, ctr).topk(k=c_b, dim=1, largest=False)[1].tolist()
+                    big = thr02[cls]
+                    for c_i in range(c_b):
+                        gid = g + c_i
+                        gt = None
+                        if task != "test":
+                            gt = int(torch.mode(labels_h[int(member_start[gid]):int(member_start[gid + 1])])[0])
+                            if gt == -100:
+                                continue
+                        ents, wts = [gid], [1.0]
+                        if float(sizes_l[gid]) > big and para_k > 0:                  # PBNet.py:199
+                            row = knn_idx[c_i]
+                            for k_i in range(para_k):
+                                ents.append(g + row[k_i + 1])
+                                wts.append(peak_v[k_i])
+                        ent_cluster += ents
+                        ent_weight += wts
+                        scene_len.append(len(ents))
+                        scene_gt.append(gt)
+                    g += c_b
+            if not scene_len:
+                return self._empty_stage(dev, task)
+
+            _sec.__exit__(None, None, None)
+            mark("a17:plan done")
+            # device gathers over points: rows of every local scene, in the reference's order
+            _sec = section("a17_gather"); _sec.__enter__()
+            ent_np = np.asarray(ent_cluster, dtype=np.int64)
+            if not torch.is_grad_enabled() or train_glue:
+                # inference: ONE launch (pbn_local_scene_rows) driven by one packed host->device copy of the entry table
+                n_ent = len(ent_cluster)
+                row_start = np.zeros(n_ent + 1, dtype=np.int32)
+                np.cumsum(sizes[ent_np], out=row_start[1:])
+                n_rows = int(row_start[-1])
+                ent_scene = np.repeat(np.arange(len(scene_len), dtype=np.int32), scene_len)
+                packed = torch.from_numpy(np.concatenate([row_start, member_start[:-1][ent_np].astype(np.int32), ent_scene,
+                                                          np.asarray(ent_weight, dtype=np.float32).view(np.int32)])).to(dev)
+                with torch.no_grad():
+                    point_idx, row_scene, coords, feat = stage_ops.local_scene_rows(
+                        packed, n_ent, n_rows, res.member_idx, ins_ind, xyz_original, LOCAL_VOXEL, point_feat_p.detach(),
+                        sem_sfp.detach(), None if (fused and not train_glue) else sem_pred_p)
+                if train_glue:
+                    # the same rows with their gradients: features and own-class scores gathered by torch, the entry weight (a
+                    # constant) taken from the fused launch's last column                                  PBNet.py:162-163,194,230
+                    row_sem_sf = sem_sfp[point_idx, sem_pred_p[point_idx]]
+                    feat = torch.cat([point_feat_p[point_idx], row_sem_sf.view(-1, 1).to(point_feat_p.dtype), feat[:, -1:]], 1)
+                elif fused:
+                    self._last_sizes.update(clusters=int(n_clt), entries=int(n_ent), rows=int(n_rows))
+            else:
+                ent_cluster_t = torch.from_numpy(ent_np)
+                ent_rows = torch.from_numpy(sizes.astype(np.int64))[ent_cluster_t]
+                member_start = torch.from_numpy(member_start)
+                ent_scene = torch.repeat_interleave(torch.arange(len(scene_len)), torch.tensor(scene_len))
+                d = lambda t: t.to(dev)
+                row_ent = torch.repeat_interleave(torch.arange(len(ent_cluster), device=dev), d(ent_rows))
+                ent_first = d(torch.cumsum(ent_rows, 0) - ent_rows)
+                pos_in_ent = torch.arange(row_ent.shape[0], device=dev) - ent_first[row_ent]
+                member_pos = d(member_start[:-1][ent_cluster_t])[row_ent] + pos_in_ent
+                local_idx = res.member_idx[member_pos].long()                            # index into the grouped array
+                point_idx = ins_ind[local_idx]                                           # index into the scene's points
+                row_scene = d(ent_scene)[row_ent]
+                row_weight = d(torch.tensor(ent_weight, dtype=torch.float32))[row_ent]
+                row_sem_sf = sem_sfp[point_idx, sem_pred_p[point_idx]]                    # PBNet.py:162-163: own-class score
+                feat = torch.cat([point_feat_p[point_idx], row_sem_sf.view(-1, 1).to(point_feat_p.dtype),
+                                  row_weight.view(-1, 1).to(point_feat_p.dtype)], 1)     # [R, 34]  PBNet.py:194,230
+                coords = torch.cat([row_scene.view(-1, 1).to(torch.int32),
+                                    torch.floor(xyz_original[point_idx] / LOCAL_VOXEL).to(torch.int32)], 1)
+            n_scenes = len(scene_len)
         out = {}
         _sec.__exit__(None, None, None)
 
@@ -465,15 +489,15 @@ class PBNet(nn.Module):
         coords3 = feat3 = None
         with section("a19_proposals"):
             if fused_glue:
-                out["proposals"], coords3, feat3 = self._proposals_fused(row_scene, point_idx, mask_score, len(scene_len),
+                out["proposals"], coords3, feat3 = self._proposals_fused(row_scene, point_idx, mask_score, n_scenes,
                                                                          xyz_original, point_feat_p)
             elif train_glue:
                 with torch.no_grad():
-                    out["proposals"], coords3, _ = self._proposals_fused(row_scene, point_idx, mask_score.detach(), len(scene_len),
+                    out["proposals"], coords3, _ = self._proposals_fused(row_scene, point_idx, mask_score.detach(), n_scenes,
                                                                          xyz_original, point_feat_p.detach())
                 feat3 = point_feat_p[out["proposals"][0][:, 1]]
             else:
-                out["proposals"] = self.get_proposal(row_scene, point_idx, mask_score, n_scenes=len(scene_len))
+                out["proposals"] = self.get_proposal(row_scene, point_idx, mask_score, n_scenes=n_scenes)
 
         mark("a19:proposals queued")
         # (a20) score branch
@@ -514,6 +538,63 @@ class PBNet(nn.Module):
             out["clt_scores"] = torch.zeros(0, dtype=torch.float32, device=dev)
         mark("a20:score branch queued")
         return out
+
+    def _device_front(self, s1, xyz_original, nb, n_cls):
+        """Class gate -> selection -> grouping -> local-scene plan without a host decision in between (inference).
+        Returns None (fall back to the host path), "empty", or (ins_ind, res, packed, n_ent, n_rows, n_clt, m)."""
+        from .. import planned as P
+        from .. import _native as N
+        import ctypes
+        dev = xyz_original.device
+        lib = N.lib()
+        vp = ctypes.c_void_p
+        consts = self.__dict__.setdefault("_front_consts", {})
+        c = consts.get(dev)
+        if c is None:
+            thr05, thr02 = self._class_thresholds()
+            c = consts[dev] = (torch.tensor(thr05, dtype=torch.float32, device=dev), torch.tensor(thr02, dtype=torch.float32, device=dev),
+                               torch.tensor(self._k_max_list(), dtype=torch.int32, device=dev))
+        thr05_d, thr02_d, kmax_d = c
+        n_pts = int(xyz_original.shape[0])
+        n_seg = (n_cls - 2) * nb
+        i32 = dict(dtype=torch.int32, device=dev)
+        counts = torch.zeros(P.CNT.WORDS, **i32)
+        class_base = torch.empty(n_cls, **i32)
+        seg_len = torch.empty(n_seg, **i32)
+        with section("a6_select"):
+            N.check(lib.pbn_class_gate(N.ptr(s1["table"]), N.ptr(thr05_d), n_cls, nb, n_pts, n_pts, N.ptr(class_base), N.ptr(seg_len),
+                                       vp(counts.data_ptr()), N.current_stream()), "pbn_class_gate")
+            ins_ind, ins_orig, ins_off, ins_sem = stage_ops.select_points(s1["sem_pred_p"], class_base, s1["block_hist"], xyz_original,
+                                                                          s1["offset_pred_p"].detach(), n_pts)
+        mark("a7:select queued")
+        with section("a7_16_grouping"):
+            res = pbnet_ops.cluster_device(ins_off, ins_orig, ins_sem, seg_len, self.radius, self.min_pts, capacity=True)
+            c_cap = min(FRONT_CLUSTER_CAP, n_pts)
+            e_cap = 7 * c_cap
+            ent = torch.empty(4 * e_cap + 1, **i32)                    # row_start (e_cap + 1) | member_start | scene | weight bits
+            wsb = int(lib.pbn_local_plan_workspace_bytes(c_cap))
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            base = ent.data_ptr()
+            N.check(lib.pbn_local_plan(N.ptr(res.cluster_num), n_seg, nb, N.ptr(res.member_start), N.ptr(res.centers),
+                                       N.ptr(res.n_clusters), N.ptr(thr02_d), N.ptr(kmax_d), c_cap, e_cap, 2 ** 31 - 1,
+                                       vp(base), vp(base + 4 * (e_cap + 1)), vp(base + 4 * (2 * e_cap + 1)),
+                                       vp(base + 4 * (3 * e_cap + 1)), vp(counts.data_ptr()), N.ptr(ws), wsb, N.current_stream()),
+                    "pbn_local_plan")
+            mark("a7:grouping queued")
+            h = torch.cat([counts, res.n_clusters]).cpu().tolist()                    # the ONE read-back of the front
+            mark("a7:grouping done")
+        if h[P.CNT.WORDS] < 0:
+            raise RuntimeError("grouping rejected its input (class id outside [2,19])")
+        if h[P.CNT.OVERFLOW] & 32:
+            raise AssertionError("batch index outside [0, cluster_batch)")            # PBNet.py:286
+        if h[P.CNT.OVERFLOW]:
+            return None                                                               # more clusters than the plan holds: host path
+        m, n_clt, n_ent, n_rows = h[P.CNT.POINTS], h[P.CNT.CLUSTERS], h[P.CNT.ENTRIES], h[P.CNT.ROWS]
+        if m == 0 or n_clt == 0 or n_ent == 0:
+            return "empty"
+        packed = torch.cat([ent[:n_ent + 1], ent[e_cap + 1:e_cap + 1 + n_ent], ent[2 * e_cap + 1:2 * e_cap + 1 + n_ent],
+                            ent[3 * e_cap + 1:3 * e_cap + 1 + n_ent]])
+        return ins_ind, res, packed, n_ent, n_rows, n_clt, m
 
     def _class_thresholds(self):
         """Per-class population gates as Python floats of the fp32 products (PBNet.py:157 `count_mean * 0.05`,

@@ -222,3 +222,35 @@ def test_degenerate_inputs_return_or_raise(setup):
     run(np.stack([np.linspace(0, 3, 3000), np.zeros(3000), np.zeros(3000)], 1), 4)      # a line
     assert run(rng.random((4000, 3)) * 0.5 - 2.0, 9) == 0               # sparse cloud at negative coordinates: no core
     assert run(np.concatenate([rng.random((3000, 3)) * 0.1, rng.random((3000, 3)) * 0.1 + 5.0]), 19) >= 2   # two far blobs
+
+
+def test_device_front_equals_host_front_and_falls_back(setup, monkeypatch):
+    """Round 5: the inference forward's gate / selection / grouping / local-scene plan on the device (two read-backs) against the
+    host path (three read-backs + the cdist / topk plan in Python): bit-identical outputs on scenes with and without
+    multi-entry local scenes; with a plan capacity of ONE cluster the device front reports overflow and the call is served by
+    the host path -- again the same outputs."""
+    import pbnet_amd.network.PBNet as PB
+    cfg, model, _, _, _ = setup
+    dev = "cuda:0"
+
+    def run(b, t):
+        with torch.no_grad():
+            r = model(b["feat_voxel"], b["xyz_voxel"], b["xyz_original"], b["v2p_index"], None, 1, "test", teacher=t)
+        return [r["proposals"][0].cpu(), r["proposals"][1].cpu(), r["proposals"][2].cpu(), r["proposals"][3].cpu(), r["clt_scores"].cpu(),
+                r["sem_pred_p"].cpu()]
+
+    for seed, boxes, room in ((1, 6, (1.6, 1.3, 1.2)), (4, 12, (2.4, 2.0, 1.4)), (5, 2, (1.2, 1.0, 1.0))):
+        b, t, _ = synth.make_val_batch(seed=seed, copies=3, room=room, n_boxes=boxes, pitch=0.03, classes=(17, 10, 5))
+        b = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+        t = {k: torch.from_numpy(v).to(dev) for k, v in t.items()}
+        monkeypatch.setattr(PB, "DEVICE_FRONT", False)
+        host = run(b, t)
+        monkeypatch.setattr(PB, "DEVICE_FRONT", True)
+        devf = run(b, t)
+        monkeypatch.setattr(PB, "FRONT_CLUSTER_CAP", 1)
+        fell = run(b, t)
+        monkeypatch.setattr(PB, "FRONT_CLUSTER_CAP", 1024)
+        assert host[1].shape[0] > 1, "the scene yields proposals"
+        for h, d, f in zip(host, devf, fell):
+            assert h.dtype == d.dtype and torch.equal(h, d)
+            assert torch.equal(h, f)
