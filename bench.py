@@ -183,7 +183,7 @@ def inflight_streams(device, n):
 def planned_leg(model, b, t, dtype, inflight, device, steps, graph):
     """The sync-free forward (pbnet_amd/planned.py: every data-dependent size stays on the device) on `inflight` streams, eager
     launch sequence or HIP-graph replay: scenes/s, and one scene alone in ms.  The difference to the headline (the size-exact
-    forward with its two read-backs) is what the host costs."""
+    forward with its five read-backs: three pyramids' level counts, the front, the proposal counts) is what the host costs."""
     r = Runner(model, b, t, inflight, device, mode="graph" if graph else "planned", dtype=dtype)
     r.run(2 * inflight)
     bl = []
@@ -802,7 +802,7 @@ def main():
                 del b32, t32
                 # configs[4]: fp16 feature slabs, int32 coordinates, the WHOLE forward replayed from a HIP graph (planned.py), one
                 # graph per stream; and the same sync-free forward in the headline's dtype, eager and from graphs: the distance
-                # to the headline is the host's share (two read-backs + the Python of the eager forward)
+                # to the headline is the host's share (five read-backs + the Python of the eager forward)
                 legs["graph_f16"] = planned_leg(model, b, t, torch.float16, args.inflight, device, k, graph=True)
                 legs["graph_f16"]["note"] = ("configs[4]: fp16 slabs + int32 coordinates, MinkUNet34C, whole PBNet.forward from a HIP "
                                              "graph per stream (capacity-planned forward, no host read-back inside)")
