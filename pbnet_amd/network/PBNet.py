@@ -48,6 +48,9 @@ PLANNED_SLACK = float(os.environ.get("PBNET_PLANNED_SLACK", "1.25"))
 # tests/test_planned_gpu.py pins to the host plan); more than FRONT_CLUSTER_CAP clusters -> the host path.  "0": the host path.
 DEVICE_FRONT = os.environ.get("PBNET_DEVICE_FRONT", "1") == "1"
 FRONT_CLUSTER_CAP = 1024
+# ... and only up to this many points: the front's buffers, fills and grids are sized by the number of POINTS where the host path sizes
+# them by the selected points; on the 1.1 M-point configs[3] scene that costs more than the saved read-back (67.9 -> 65.8 scenes/s in flight)
+FRONT_MAX_POINTS = int(os.environ.get("PBNET_DEVICE_FRONT_MAX_POINTS", "400000"))
 
 
 def _mlp(cin, mid, cout, sigmoid=False):
@@ -292,7 +295,8 @@ class PBNet(nn.Module):
 
         # inference: gate, selection, grouping and local-scene plan on the device, ONE read-back (see DEVICE_FRONT)
         front = None
-        if DEVICE_FRONT and fused and not train_glue and task == "test" and ins_label is None and xyz_original.is_contiguous():
+        if (DEVICE_FRONT and fused and not train_glue and task == "test" and ins_label is None and xyz_original.is_contiguous()
+                and xyz_original.shape[0] <= FRONT_MAX_POINTS):
             front = self._device_front(s1, xyz_original, nb, n_cls)
             if isinstance(front, str):
                 return self._empty_stage(dev, task)
