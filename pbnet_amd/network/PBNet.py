@@ -49,8 +49,8 @@ PLANNED_SLACK = float(os.environ.get("PBNET_PLANNED_SLACK", "1.25"))
 DEVICE_FRONT = os.environ.get("PBNET_DEVICE_FRONT", "1") == "1"
 FRONT_CLUSTER_CAP = 1024
 # ... and only up to this many points: the front's buffers, fills and grids are sized by the number of POINTS where the host path sizes
-# them by the selected points; on the 1.1 M-point configs[3] scene that costs more than the saved read-back (67.9 -> 65.8 scenes/s in flight)
-FRONT_MAX_POINTS = int(os.environ.get("PBNET_DEVICE_FRONT_MAX_POINTS", "400000"))
+# them by the selected points: +1-2 % in flight at 162 k points, level at 323 k, -4.5 % at 485 k (the 3-copy batch), -3 % on the 1.1 M-point configs[3] scene
+FRONT_MAX_POINTS = int(os.environ.get("PBNET_DEVICE_FRONT_MAX_POINTS", "250000"))
 
 
 def _mlp(cin, mid, cout, sigmoid=False):
