@@ -236,6 +236,10 @@ __global__ __launch_bounds__(TPB) void k_count(const float4* __restrict__ spt, c
     const int n = n_ref.get();
     if (n <= 0) return;
     const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
+    // capacity mode: a wave whose first point is past the count has nothing to do (round 5: its lanes used to be folded onto point
+    // n - 1 and repeat that point's whole neighbourhood walk -- 0.27 -> 1.9 ms at 7.5 x capacity); only the wave that straddles
+    // the count keeps its idle lane groups, for the shuffles
+    if ((t - (threadIdx.x & 63)) / NB_Q >= n) return;
     int p = (int)(t / NB_Q);
     const int q = (int)(t % NB_Q);
     const bool live = p < n;
@@ -459,6 +463,7 @@ __global__ __launch_bounds__(TPB) void k_border(const float4* __restrict__ spt, 
                                                int* __restrict__ lab, const int* __restrict__ cell_rep) {
     const int n = n_ref.get();
     const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (n <= 0 || (t - (threadIdx.x & 63)) / NB_Q >= n) return;   // (as in k_count: whole waves past the count leave)
     int p = (int)(t / NB_Q);
     const int q = (int)(t % NB_Q);
     const bool live = p < n;
@@ -561,6 +566,7 @@ __global__ __launch_bounds__(TPB) void k_relabel(const int* __restrict__ lab, co
     const int n = n_ref.get();
     if (n <= 0) return;   // capacity mode with nothing selected
     int i = blockIdx.x * TPB + threadIdx.x;
+    if (i - (int)(threadIdx.x & 63) >= n) return;   // whole waves past the count leave
     const bool live = i < n;
     if (!live) i = n - 1;  // keep whole waves alive for the shuffles below; duplicates of the last point are harmless
     const int s = lab[i];

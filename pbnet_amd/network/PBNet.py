@@ -49,8 +49,9 @@ PLANNED_SLACK = float(os.environ.get("PBNET_PLANNED_SLACK", "1.25"))
 DEVICE_FRONT = os.environ.get("PBNET_DEVICE_FRONT", "1") == "1"
 FRONT_CLUSTER_CAP = 1024
 # ... and only up to this many points: the front's buffers, fills and grids are sized by the number of POINTS where the host path sizes
-# them by the selected points: +1-2 % in flight at 162 k points, level at 323 k, -4.5 % at 485 k (the 3-copy batch), -3 % on the 1.1 M-point configs[3] scene
-FRONT_MAX_POINTS = int(os.environ.get("PBNET_DEVICE_FRONT_MAX_POINTS", "250000"))
+# them by the selected points.  (Measured after k_count stopped folding the lanes past the count onto its last point: +2.5-3.5 % in
+# flight at 162 k points, level at 485 k and at 1.1 M points.)
+FRONT_MAX_POINTS = int(os.environ.get("PBNET_DEVICE_FRONT_MAX_POINTS", "1000000"))
 
 
 def _mlp(cin, mid, cout, sigmoid=False):
