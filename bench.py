@@ -58,7 +58,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_SUMMARIES = ("r05_e_pmc_summary.json", "r05_d_pmc_summary.json", "r05_c_pmc_summary.json", "r05_b_pmc_summary.json", "r05_a_pmc_summary.json", "r04_d_pmc_summary.json", "r04_c_pmc_summary.json", "r04_b_pmc_summary.json", "r04_a_pmc_summary.json", "r03_c_pmc_summary.json", "r03_b_pmc_summary.json", "r03_a_pmc_summary.json", "r02_b_pmc_summary.json", "r02_a_pmc_summary.json", "r01_pmc_summary.json")   # newest first
+PMC_SUMMARIES = ("r05_f_pmc_summary.json", "r05_e_pmc_summary.json", "r05_d_pmc_summary.json", "r05_c_pmc_summary.json", "r05_b_pmc_summary.json", "r05_a_pmc_summary.json", "r04_d_pmc_summary.json", "r04_c_pmc_summary.json", "r04_b_pmc_summary.json", "r04_a_pmc_summary.json", "r03_c_pmc_summary.json", "r03_b_pmc_summary.json", "r03_a_pmc_summary.json", "r02_b_pmc_summary.json", "r02_a_pmc_summary.json", "r01_pmc_summary.json")   # newest first
 
 
 WORKLOADS = {
@@ -340,7 +340,7 @@ def gpu_active(args):
     if args.copies != 1 or args.dtype != "bf16" or args.workload != "c2":
         return None
     out = {}
-    for tag in ("r05_e", "r05_d", "r05_c", "r05_b", "r05_a"):
+    for tag in ("r05_f", "r05_e", "r05_d", "r05_c", "r05_b", "r05_a"):
         for key, name in (("in_flight", "%s_bench_concurrency.json" % tag), ("one_scene", "%s_inflight1_concurrency.json" % tag),
                           ("in_flight_planned_eager", "%s_planned_concurrency.json" % tag),
                           ("in_flight_graph", "%s_graph_concurrency.json" % tag)):
