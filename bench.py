@@ -626,9 +626,7 @@ def main():
 
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     cfg, model, b, t, info, raw = build_workload(rank, args.copies, dtype, device, args.workload, world)
-    # the headline is the SIZE-EXACT forward (every scene new to the model, as in the reference's test loop), whatever the
-    # environment says; the opt-in capacity cache for repeated input sizes (PBNet.forward, PBNET_PLANNED_CACHE) is its own leg below
-    model.planned_cache = False
+    # the headline is the SIZE-EXACT forward (every scene new to the model, as in the reference's test loop)
     phase("build_workload")
 
     def barrier():
@@ -810,13 +808,6 @@ def main():
                                    "graph": planned_leg(model, b, t, dtype, args.inflight, device, k, graph=True),
                                    "note": "the sync-free forward in the headline's dtype; headline = eager PBNet.forward with its "
                                            "read-backs"}
-                model.planned_cache = True      # PBNet.forward itself, repeated input sizes: the planned sequence from the 2nd call of a thread
-                v, ms, alone, _ = timed_leg(model, b, t, args.inflight, device, k, warmup=4 * args.inflight)   # (pools grow to the capacities)
-                legs["planned"]["cached_forward"] = {"value": round(v, 3), "unit": "scenes/s", "ms_per_step": round(ms, 3),
-                                                     "one_scene_in_flight_ms_per_scene": round(alone, 3),
-                                                     "forward_path": model.forward_path(),
-                                                     "note": "model(...) with the opt-in capacity cache (PBNET_PLANNED_CACHE=1): one read-back per forward from the second call of an input size"}
-                model.planned_cache = False
                 phase("planned_legs")
                 # three DISTINCT scenes per forward through the batch index: every launch of the coarse levels gets 3x the rows
                 bb, tb, ib = build_batched((2, 4, 5), dtype, device)
@@ -883,7 +874,7 @@ def main():
                                       info["n_points"] // args.copies, info["n_voxels"] // args.copies,
                                       WORKLOADS[args.workload]["voxel"] * 100, args.copies,
                                       "y" if args.copies == 1 else "ies"),
-                       "forward_path": "size-exact (the opt-in capacity cache is measured as legs.planned.cached_forward)" if args.forward_mode == "size-exact" else args.forward_mode + " (pbnet_amd/planned.py, capacities 1.25 x this scene's sizes; NOT the headline configuration)",
+                       "forward_path": "size-exact" if args.forward_mode == "size-exact" else args.forward_mode + " (pbnet_amd/planned.py, capacities 1.25 x this scene's sizes; NOT the headline configuration)",
                        "points_per_step": info["n_points"], "voxels_per_step": info["n_voxels"],
                        "proposals_per_step": n_prop, "scenes_in_flight_per_gpu": args.inflight,
                        "one_scene_in_flight_ms_per_scene": None if single_ms is None else round(single_ms, 3),

@@ -251,7 +251,9 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
     static const int rs_tab_env = getenv("PBN_UNET_RS_TABLES") ? atoi(getenv("PBN_UNET_RS_TABLES")) : 0;
     void* rs_tab[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool rs_tab_built[5] = {false, false, false, false, false};
-    if (rs_tab_env && dtype != PBN_F32 && splitk_ws && k3) {
+    // (not in capacity mode: the launches cut their tiles for the rows expected or counted on the device, tables built for the
+    // capacity would never match their geometry)
+    if (rs_tab_env && dtype != PBN_F32 && splitk_ws && k3 && !n_rows_dev) {
         size_t need = 0;
         size_t bytes[5] = {0, 0, 0, 0, 0};
         for (int l = 0; l < 5; ++l) {

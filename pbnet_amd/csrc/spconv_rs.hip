@@ -55,6 +55,7 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rs(const ConvArgs a, const in
     // capacity form (n_out is a capacity, the rows that exist are counted on the device) WITHOUT a rows hint: the launch's tiles share
     // the rows that exist -- a tile height sized by the capacity would leave the last workgroups without work and the others with too
     // much.  With a hint (n_sel < n_out) the tiles were cut for the rows expected and those behind the count simply exit
+    if (n <= 0) return;                   // (a device-side count of 0: no tile height to cut, nothing to write)
     const int tile_rows = (a.n_out_dev && a.n_sel == a.n_out) ? min(tile_rows_launch, (((n + n_tiles - 1) / n_tiles) + 15) & ~15) : tile_rows_launch;
     // tiles that have rows (the launch may hold more: capacities); the XCD-aware map runs over THOSE, so that every XCD gets the
     // same share of working tiles (mapped over the launch's tiles, the last XCDs would hold only empty ones)
@@ -705,6 +706,7 @@ __global__ __launch_bounds__(RS_TPB) void k_spconv_rsh(const ConvArgs a, const i
     const int g = lane >> 4, rl = lane & 15;
     const int n = a.n_out_dev ? min(*a.n_out_dev, a.n_out) : a.n_out;
     // capacity form: the launch's tiles share the rows that exist (see k_spconv_rs); the LDS layout stays the launch's
+    if (n <= 0) return;                   // (a device-side count of 0: no tile height to cut, nothing to write)
     const int tile_rows = (a.n_out_dev && a.n_sel == a.n_out) ? min(tile_rows_launch, (((n + n_tiles - 1) / n_tiles) + 15) & ~15) : tile_rows_launch;
     const int n_work = (n + tile_rows - 1) / tile_rows;       // tiles that have rows: the XCD-aware map runs over those (see k_spconv_rs)
     if ((int)blockIdx.x >= n_work) return;

@@ -32,15 +32,6 @@ HEAD_CLUSTERS = 256                                                   # clusters
 MASK_THD = 0.45                                                       # PBNet.py:317
 # training: index-only glue between the networks on the inference path's fused launches (see PBNet.forward); "0" = plain torch
 TRAIN_FUSED_GLUE = os.environ.get("PBNET_TRAIN_FUSED_GLUE", "1") == "1"
-# Round 5, opt-in (PBNET_PLANNED_CACHE=1 or model.planned_cache = True): inference calls whose input SIZES repeat (the same scene
-# again, rotated copies, a fixed-size stream) take the sync-free launch sequence of pbnet_amd/planned.py: the first call of a size
-# runs the size-exact forward below and records every data-dependent size; later calls of that size (any host thread of the
-# process) run the same kernels over buffers of 1.25 x those sizes with the counts kept on the device and ONE read-back at the
-# end instead of three.  Same integers, scores within fp32 re-association of the first call's (a padded level may pick another
-# tile shape: tests/test_planned_gpu.py) -- which is why it is not the default: the size-exact path returns the same bits for the
-# same input every time.  An exceeded capacity or any failure of the planned path falls back to the size-exact forward.
-PLANNED_CACHE = os.environ.get("PBNET_PLANNED_CACHE", "0") == "1"
-PLANNED_SLACK = float(os.environ.get("PBNET_PLANNED_SLACK", "1.25"))
 # Round 5: the size-exact inference forward takes its class gate, the selection, the grouping AND the local-scene plan on the
 # device (csrc/plan.hip: pbn_class_gate / pbn_local_plan, the entries the planned forward uses) over buffers bounded by the
 # number of points, and reads the four sizes back ONCE where it used to read the class table, then the cluster table, and run
@@ -91,9 +82,8 @@ class PBNet(nn.Module):
         self.soft_max = ME.MinkowskiSoftmax()
         self.weight_initialization()
         self.fix_module = []
-        self.planned_cache = PLANNED_CACHE      # instance switch (tests of the size-exact path set it to False)
 
-    # per host thread: the sizes of its last forward, its planned forwards (several scenes in flight share one model)
+    # per host thread: the sizes of its last forward (several scenes in flight share one model)
     @property
     def _tls(self):
         t = self.__dict__.get("_tls_obj")
@@ -104,7 +94,6 @@ class PBNet(nn.Module):
     def __getstate__(self):                     # (a threading.local cannot be copied / pickled: deepcopy, torch.save of the module)
         d = self.__dict__.copy()
         d.pop("_tls_obj", None)
-        d.pop("_planned_obj", None)
         return d
 
     @property
@@ -114,77 +103,6 @@ class PBNet(nn.Module):
     @_last_sizes.setter
     def _last_sizes(self, v):
         self._tls.last_sizes = v
-
-    def forward_path(self):
-        """"planned" if this thread's last inference forward ran the capacity-planned launch sequence, else "size-exact"."""
-        return self._tls.__dict__.get("path", "size-exact")
-
-    def _planned_key(self, feat_voxel, xyz_original, teacher):
-        return (int(xyz_original.shape[0]), int(feat_voxel.shape[0]), feat_voxel.dtype, torch.cuda.current_device(), teacher is not None)
-
-    def _planned_cache(self):
-        c = self.__dict__.get("_planned_obj")
-        if c is None:
-            c = self.__dict__.setdefault("_planned_obj", {"lock": threading.Lock(), "entries": {}})
-        return c
-
-    def _planned_try(self, feat_voxel, xyz_voxel, xyz_original, v2p_v1, teacher):
-        """The planned forward for inputs of these sizes, if a size-exact forward has recorded them; None -> run the size-exact
-        forward.  The capacities are shared by the host threads of the process; a PlannedForward object serves one call at a
-        time (checked out of the entry's free list), so scenes in flight on several threads never share per-call state."""
-        c = self._planned_cache()
-        with c["lock"]:
-            ent = c["entries"].get(self._planned_key(feat_voxel, xyz_original, teacher))
-            if ent is None or ent["disabled"] or ent["stale"]:
-                return None
-            pf = ent["free"].pop() if ent["free"] else None
-            cap = ent["cap"]
-        from .. import planned as P
-        try:
-            if pf is None:
-                pf = P.PlannedForward(self, cap, dtype=feat_voxel.dtype)
-            out = pf(feat_voxel, xyz_voxel, xyz_original, v2p_v1, teacher=teacher)
-        except P.CapacityOverflow:
-            with c["lock"]:
-                if ent["cap"] is cap:
-                    ent["stale"], ent["free"] = True, []      # the size-exact forward below re-measures; capacities only grow
-            return None
-        except Exception as e:                    # noqa: BLE001 -- never let the fast path take the call down
-            ent["disabled"] = True
-            import sys
-            sys.stderr.write("pbnet_amd: planned forward disabled for %r after %s: %s\n" % (ent["key"], type(e).__name__, str(e)[:200]))
-            return None
-        with c["lock"]:
-            if ent["cap"] is cap and len(ent["free"]) < 16:
-                ent["free"].append(pf)
-        out.pop("counts", None)
-        return out
-
-    def _planned_record(self, feat_voxel, xyz_original, teacher):
-        """After a complete size-exact inference forward: remember its sizes as the capacities of the next calls of this size."""
-        s = self._last_sizes
-        if not all(k in s for k in ("lv1", "lv2", "lv3", "points", "clusters", "entries", "rows")):
-            return
-        from .. import planned as P
-        key = self._planned_key(feat_voxel, xyz_original, teacher)
-        cap = P.Capacities(n_points=key[0], n_voxels=key[1], lv1=list(s["lv1"]), lv2=list(s["lv2"]), lv3=list(s["lv3"]),
-                           points=int(s["points"]), clusters=int(s["clusters"]), entries=int(s["entries"]), rows=int(s["rows"]))
-        c = self._planned_cache()
-        with c["lock"]:
-            entries = c["entries"]
-            old = entries.get(key)
-            if old is not None and not old["stale"]:
-                return
-            if old is not None:                       # grew past the plan: keep the larger of every size
-                o = old["measured"]
-                cap = P.Capacities(n_points=key[0], n_voxels=key[1], lv1=[max(a, b) for a, b in zip(cap.lv1, o.lv1)],
-                                   lv2=[max(a, b) for a, b in zip(cap.lv2, o.lv2)], lv3=[max(a, b) for a, b in zip(cap.lv3, o.lv3)],
-                                   points=max(cap.points, o.points), clusters=max(cap.clusters, o.clusters),
-                                   entries=max(cap.entries, o.entries), rows=max(cap.rows, o.rows))
-            elif len(entries) >= 8:
-                entries.pop(next(iter(entries)))
-            entries[key] = {"key": key, "measured": cap, "cap": cap.padded(PLANNED_SLACK), "free": [], "stale": False,
-                            "disabled": False}
 
     def weight_initialization(self):
         for m in self.modules():
@@ -202,15 +120,6 @@ class PBNet(nn.Module):
         if feat_voxel.shape[0] == 0 or xyz_original.shape[0] == 0:
             raise ValueError("PBNet.forward: empty scene (0 voxels / 0 points)")
         fused = not torch.is_grad_enabled()           # inference: the stage glue runs as fused launches (stage_ops)
-        plannable = (getattr(self, "planned_cache", False) and fused and task == "test" and ins_label is None and epoch > self.cluster_epoch
-                     and feat_voxel.is_cuda and xyz_voxel.is_cuda and xyz_original.is_cuda and v2p_v1.is_cuda
-                     and feat_voxel.dtype in (torch.bfloat16, torch.float16, torch.float32))
-        self._tls.path = "size-exact"
-        if plannable:
-            out = self._planned_try(feat_voxel, xyz_voxel, xyz_original, v2p_v1, teacher)
-            if out is not None:
-                self._tls.path = "planned"
-                return out
         stage1 = self.backbone_stage(feat_voxel.to(dev), xyz_voxel.to(dev), v2p_v1.to(dev), fused)
         if teacher is not None:
             stage1["sem_pred_score_p"] = teacher["sem_score"].to(dev, stage1["sem_pred_score_p"].dtype)
@@ -238,8 +147,6 @@ class PBNet(nn.Module):
         if epoch > self.cluster_epoch:
             ret.update(self.cluster_stage(stage1, xyz_original.to(dev), None if ins_label is None else ins_label.to(dev),
                                           task))
-            if plannable:
-                self._planned_record(feat_voxel, xyz_original, teacher)
         return ret
 
     # ---- PBNet.py:117-136 -------------------------------------------------------------------------------------

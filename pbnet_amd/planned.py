@@ -75,13 +75,8 @@ class Capacities(object):
 
 def measure_capacities(model, feat_voxel, xyz_voxel, xyz_original, v2p_index, teacher=None):
     """One size-exact forward that records every data-dependent size (PBNet._last_sizes)."""
-    keep = getattr(model, "planned_cache", False)
-    model.planned_cache = False                 # the size-exact forward, whatever the model's cache holds for these sizes
-    try:
-        with torch.no_grad():
-            model(feat_voxel, xyz_voxel, xyz_original, v2p_index, None, 1, "test", teacher=teacher)
-    finally:
-        model.planned_cache = keep
+    with torch.no_grad():
+        model(feat_voxel, xyz_voxel, xyz_original, v2p_index, None, 1, "test", teacher=teacher)
     s = model._last_sizes
     return Capacities(n_points=int(xyz_original.shape[0]), n_voxels=int(feat_voxel.shape[0]), lv1=list(s["lv1"]),
                       lv2=list(s.get("lv2", [1] * 5)), lv3=list(s.get("lv3", [1] * 5)), points=int(s.get("points", 1)),

@@ -1,8 +1,6 @@
 """Manual stress (not collected by pytest): N random scenes of different sizes, each evaluated once alone, then ROUNDS times
 by WORKERS host threads on their own HIP streams in shuffled order (bf16 slabs, the bench configuration).  Every in-flight
-result must equal the stand-alone result bit for bit.  usage: fuzz_inflight.py [scenes=8] [workers=4] [rounds=6]
-FUZZ_CACHE=1: the same with PBNet.forward's opt-in capacity cache on (fp32 slabs): the planned launch sequence serves every call
-after the first of a scene; integers must be identical, scores within 1e-4 (a padded level may pick another tile shape)."""
+result must equal the stand-alone result bit for bit.  usage: fuzz_inflight.py [scenes=8] [workers=4] [rounds=6]"""
 import sys, os, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -20,9 +18,6 @@ torch.manual_seed(22)
 model = PBNet(cfg).to(dev).eval()
 for p in model.parameters():
     p.data = p.data.to(torch.float32)
-CACHE = os.environ.get("FUZZ_CACHE", "0") == "1"
-model.planned_cache = False
-paths = {"planned": 0, "size-exact": 0}
 scenes = []
 for seed in range(1, NS + 1):
     rng = np.random.default_rng(100 + seed)
@@ -32,7 +27,7 @@ for seed in range(1, NS + 1):
     batch, teacher, info = synth.make_val_batch(seed=seed, copies=int(rng.integers(1, 4)), room=room, n_boxes=nb,
                                                 pitch=float(rng.choice([0.0225, 0.03])), classes=classes)
     b = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
-    b["feat_voxel"] = b["feat_voxel"].to(torch.float32 if CACHE else torch.bfloat16)
+    b["feat_voxel"] = b["feat_voxel"].to(torch.bfloat16)
     t = {k: torch.from_numpy(v).to(dev) for k, v in teacher.items()}
     scenes.append((b, t, info["n_points"]))
 
@@ -41,21 +36,17 @@ def run(i):
     b, t, _ = scenes[i]
     with torch.no_grad():
         r = model(b["feat_voxel"], b["xyz_voxel"], b["xyz_original"], b["v2p_index"], None, 1, "test", teacher=t)
-    paths[model.forward_path()] += 1
     return [r["proposals"][0].cpu(), r["proposals"][1].cpu(), r["proposals"][3].float().cpu(), r["clt_scores"].float().cpu(),
             r["sem_pred_p"].cpu()]
 
 
 want = [run(i) for i in range(NS)]
 torch.cuda.synchronize()
-model.planned_cache = CACHE
 
 
 def same(a, b):
     if a.shape != b.shape:
         return False
-    if CACHE and a.is_floating_point():
-        return bool((a - b).abs().max() <= 1e-4) if a.numel() else True
     return torch.equal(a, b)
 
 
@@ -80,5 +71,5 @@ def worker(w):
 ths = [threading.Thread(target=worker, args=(w,)) for w in range(WORKERS)]
 for th in ths: th.start()
 for th in ths: th.join()
-print("forwards in flight: %d, mismatches: %d, errors: %d" % (WORKERS * ROUNDS * NS, len(bad), len(errors)), bad[:5], errors[:2], paths)
+print("forwards in flight: %d, mismatches: %d, errors: %d" % (WORKERS * ROUNDS * NS, len(bad), len(errors)), bad[:5], errors[:2])
 sys.exit(1 if bad or errors else 0)

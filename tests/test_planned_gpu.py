@@ -36,7 +36,6 @@ def _build_model():
 @pytest.fixture(scope="module")
 def model():
     m = _build_model()
-    m.planned_cache = False                       # `model(...)` below is the size-exact path the planned one is compared with
     return m
 
 
@@ -91,59 +90,6 @@ def test_padded_capacities_and_other_scenes(model):
     flip = torch.rand(t2["sem_score"].shape[0], device=DEV) < 0.01
     t2["sem_score"][flip] = t2["sem_score"][flip].roll(3, dims=1)
     _same_proposals(pf(*_args(b), teacher=t2), _eager(model, b, t2), 1e-5)
-
-
-def test_forward_capacity_cache(model):
-    """PBNet.forward with its capacity cache on (the package default): the first call of an input size runs the size-exact path and
-    records the sizes, the next calls of that size -- from any host thread -- run the planned sequence and return the same
-    proposals; other teacher outputs that outgrow the recorded capacities fall back and re-plan; other sizes are not affected."""
-    import threading
-    m = _build_model()                            # the same weights (same seeds) as the fixture
-    m.planned_cache = True
-    b, t = _scene()
-    want = _eager(model, b, t)
-    first = _eager(m, b, t)
-    assert m.forward_path() == "size-exact"
-    _same_proposals(first, want, 0.0)
-    again = _eager(m, b, t)
-    assert m.forward_path() == "planned" and "counts" not in again
-    _same_proposals(again, want, 1e-5)
-    got, paths = {}, {}
-
-    def worker(i):
-        st = torch.cuda.Stream(DEV)
-        with torch.cuda.stream(st):
-            for _ in range(3):
-                got[i] = _eager(m, b, t)
-            paths[i] = m.forward_path()
-        st.synchronize()
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
-    [x.start() for x in th]
-    [x.join() for x in th]
-    torch.cuda.synchronize()
-    for i in range(3):
-        assert paths[i] == "planned"
-        _same_proposals(got[i], want, 1e-5)
-    # a scene of another size: its own first call is size-exact
-    b2, t2 = _scene(seed=3, n_boxes=4)
-    if b2["xyz_original"].shape[0] != b["xyz_original"].shape[0]:
-        _eager(m, b2, t2)
-        assert m.forward_path() == "size-exact"
-    # the same input sizes with every point in one instance class more: capacities of the cluster stage are exceeded ->
-    # this call is served by the size-exact path, the capacities grow, the call after it is planned again
-    ent = next(iter(m._planned_cache()["entries"].values()))
-    ent["cap"] = planned.Capacities(**dict({k: getattr(ent["cap"], k) for k in ent["cap"].FIELDS}, rows=8))
-    ent["free"] = []
-    out = _eager(m, b, t)
-    assert m.forward_path() == "size-exact"
-    _same_proposals(out, want, 0.0)
-    out = _eager(m, b, t)
-    assert m.forward_path() == "planned"
-    _same_proposals(out, want, 1e-5)
-    # switched off: always the size-exact path
-    m.planned_cache = False
-    _eager(m, b, t)
-    assert m.forward_path() == "size-exact"
 
 
 def test_overflow_is_reported_not_written(model):

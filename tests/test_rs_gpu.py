@@ -213,6 +213,16 @@ def test_device_side_row_count_bounds_the_launch():
         assert torch.all(out[n:] == 7.0), "rows past the device-side count were written (cfg %d)" % cfg
         exact = spconv_forward(x.F, nbr, n, packed, scale=sc, shift=sh, relu=True, rows_per_wave=32)
         assert torch.allclose(out[:n].float(), exact.float(), atol=6e-2 * max(1.0, want.abs().max().item()))
+        # a device-side count of 0 (an empty mask / score lineage over a capacity): nothing is written, nothing divides by zero
+        zero = torch.zeros(1, dtype=torch.int32, device=DEV)
+        out = torch.full((cap, cout_p), 7.0, dtype=dtype, device=DEV)
+        rc = N.lib().pbn_spconv_forward(
+            N.c_vp(feats.data_ptr()), feats.stride(0), cap, N.c_vp(nbr_cap.data_ptr()), 27, None, N.c_vp(zero.data_ptr()), cap,
+            N.c_vp(w.data_ptr()), vpo, n_steps, cout_p, N.c_vp(sc.data_ptr()), N.c_vp(sh.data_ptr()), None, 0, 1,
+            N.c_vp(out.data_ptr()), out.stride(0), _DT[dtype], cfg, N.c_vp(ws.data_ptr()), ws.numel(), N.current_stream())
+        N.check(rc, "pbn_spconv_forward")
+        torch.cuda.synchronize()
+        assert torch.all(out == 7.0), "a device-side count of 0 wrote rows (cfg %d)" % cfg
 
 
 _CHILD = r"""
