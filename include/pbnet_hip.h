@@ -184,23 +184,6 @@ int pbn_spconv_forward_dual(const void* in_feat, int ld_in, int n_in, const int3
                             size_t workspace_bytes, const void* in2_feat, int ld_in2, int n_in2, int vecs_second,
                             pbn_stream_t stream);
 
-/* Round 5: per-map tables of the staged row-stationary convolution kernels (csrc/spconv_rs.hip; the same reference call sites as
- * pbn_spconv_forward -- network/Mink.py:221-288,293-350 -- for the wide levels, stride 1 / 2).  For a k = 3 cube map (27 offsets,
- * input level = output level) pbn_rs_table_build derives ONCE per map what every launch over that map would otherwise rebuild in
- * its prologue: per tile of ~n_out / (number of CUs) output rows the tile's row order (rows sorted by their corner-offset pattern),
- * the distinct input rows outside the tile, the map as 16-bit positions into the tile's LDS stage and the per-fragment offset masks.
- * pbn_rs_table_bytes: bytes of the table (0: no table for this map).  pbn_spconv_forward_tab = pbn_spconv_forward (no processing
- * order) with such a table (NULL = none: the kernel builds the tile's tables itself); a table built for another geometry is
- * ignored.  Results do not depend on whether a table is given. */
-size_t pbn_rs_table_bytes(int n_out, int n_offsets);
-int pbn_rs_table_build(const int32_t* nbr, int n_offsets, const int32_t* n_out_dev, int n_out, void* table, size_t table_bytes,
-                       pbn_stream_t stream);
-int pbn_spconv_forward_tab(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
-                           const int32_t* n_out_dev, int n_out, const void* w_packed, int vecs_per_offset, int n_steps,
-                           int cout_padded, const float* scale, const float* shift, const void* residual, int ld_res,
-                           int relu, void* out_feat, int ld_out, int dtype, int rows_per_wave, void* workspace,
-                           size_t workspace_bytes, const void* rs_table, pbn_stream_t stream);
-
 /* out[i, :] = in[idx[i], :] on 16-byte multiples (voxel -> point gathers, network/PBNet.py:130-134,250); a negative
  * index gives a zero row (padding slots of the compacted weight-gradient operands). */
 int pbn_gather_rows(const void* in, int ld_in_bytes, const int64_t* idx, int n, int row_bytes, void* out,

@@ -239,40 +239,6 @@ def spconv_forward(feats, nbr, n_out, packed, scale=None, shift=None, residual=N
     return out
 
 
-class RsTable(object):
-    """Row-stationary tables of one k = 3 cube map (pbn_rs_table_build): built once per map, shared by every layer of the level."""
-
-    def __init__(self, nbr, n_out=None):
-        N.require_cuda(nbr)
-        assert nbr.dtype == torch.int32 and nbr.is_contiguous() and nbr.dim() == 2
-        self.nbr = nbr
-        self.n_out = int(nbr.shape[0]) if n_out is None else int(n_out)
-        nbytes = int(N.lib().pbn_rs_table_bytes(self.n_out, int(nbr.shape[1])))
-        assert nbytes > 0, "no row-stationary table for this map"
-        self.table = torch.empty(nbytes, dtype=torch.uint8, device=nbr.device)
-        N.check(N.lib().pbn_rs_table_build(N.c_vp(nbr.data_ptr()), int(nbr.shape[1]), None, self.n_out, N.c_vp(self.table.data_ptr()),
-                                           nbytes, N.current_stream()), "pbn_rs_table_build")
-
-
-def spconv_forward_tab(feats, rs_table, packed, scale=None, shift=None, residual=None, relu=False, out=None, rows_per_wave=0):
-    """pbn_spconv_forward_tab: the convolution over a map with its row-stationary tables (RsTable)."""
-    w, vpo, n_steps, cout_p = packed
-    dtype = feats.dtype
-    nbr, n_out = rs_table.nbr, rs_table.n_out
-    assert feats.stride(1) == 1 and feats.shape[1] >= vpo * _ELEMS[dtype]
-    if out is None:
-        out = torch.empty(n_out, cout_p, dtype=dtype, device=feats.device)
-    ws = _workspace(feats.device)
-    rc = N.lib().pbn_spconv_forward_tab(
-        N.c_vp(feats.data_ptr()), feats.stride(0), int(feats.shape[0]), N.c_vp(nbr.data_ptr()), int(nbr.shape[1]), None, n_out,
-        N.c_vp(w.data_ptr()), vpo, n_steps, cout_p, None if scale is None else N.c_vp(scale.data_ptr()),
-        None if shift is None else N.c_vp(shift.data_ptr()), None if residual is None else N.c_vp(residual.data_ptr()),
-        0 if residual is None else residual.stride(0), int(bool(relu)), N.c_vp(out.data_ptr()), out.stride(0), _DT[dtype],
-        int(rows_per_wave), N.c_vp(ws.data_ptr()), ws.numel(), N.c_vp(rs_table.table.data_ptr()), N.current_stream())
-    N.check(rc, "pbn_spconv_forward_tab")
-    return out
-
-
 def spconv_forward_dual(feats, nbr, n_out, feats2, packed, vpo2, shift=None, scale=None, relu=False, out=None, rows_per_wave=0):
     """pbn_spconv_forward_dual: the convolution over `nbr` plus a 1x1 over `feats2` (row o with output row o) in one reduction.
     packed = (w [steps of the map | steps of the second source (| zero padding)], vpo, n_steps_total, cout_p)."""

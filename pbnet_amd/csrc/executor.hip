@@ -244,34 +244,7 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
     if (pbn_unet_arena_bytes(bufs, n_bufs, n_rows, dtype, offs) > arena_bytes) return PBN_ERR_WORKSPACE;
     const int es = esize(dtype);
     char* A = (char*)arena;
-    // Round 5: tables of the staged row-stationary kernels (spconv_rs.hip) for the k = 3 maps of the levels where they pay, built
-    // by the first op of this call that uses them, at the END of the split-K workspace (the ops see the rest); an op over that
-    // map runs with g_rs_table set.  OFF by default (PBN_UNET_RS_TABLES=1 switches it on): measured inside the pipeline the build
-    // (~20-25 us per map and forward) costs what the layers of the level give back (spconv_rs.hip: "Where each form pays").
-    static const int rs_tab_env = getenv("PBN_UNET_RS_TABLES") ? atoi(getenv("PBN_UNET_RS_TABLES")) : 0;
-    void* rs_tab[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool rs_tab_built[5] = {false, false, false, false, false};
-    // (not in capacity mode: the launches cut their tiles for the rows expected or counted on the device, tables built for the
-    // capacity would never match their geometry)
-    if (rs_tab_env && dtype != PBN_F32 && splitk_ws && k3 && !n_rows_dev) {
-        size_t need = 0;
-        size_t bytes[5] = {0, 0, 0, 0, 0};
-        for (int l = 0; l < 5; ++l) {
-            if (!k3[l]) continue;
-            bool wanted = false;
-            for (int i = 0; i < n_ops && !wanted; ++i)
-                wanted = ops[i].map_kind == 1 && ops[i].level_out == l && rs_staged_pays(n_rows[l], ops[i].cout_p / 16);
-            if (wanted) { bytes[l] = a256(pbn_rs_table_bytes(n_rows[l], 27)); need += bytes[l]; }
-        }
-        if (need > 0 && splitk_bytes >= need + ((size_t)32 << 20)) {
-            char* end = (char*)splitk_ws + splitk_bytes;
-            end -= ((uintptr_t)end & 255);
-            for (int l = 0; l < 5; ++l)
-                if (bytes[l]) { end -= bytes[l]; rs_tab[l] = end; }
-            splitk_bytes = (size_t)(end - (char*)splitk_ws);
-        }
-    }
-    struct RsGuard { ~RsGuard() { g_rs_table = RsTableRef{nullptr, nullptr, 0}; g_rows_hint = 0; } } rs_guard;   // cleared on every return path
+    struct RsGuard { ~RsGuard() { g_rows_hint = 0; } } rs_guard;   // cleared on every return path
     auto base = [&](int b) -> char* { return b == 0 ? (char*)input : A + offs[b]; };
     auto ld = [&](int b) -> int { return b == 0 ? ld_input : bufs[b].width; };
     for (int i = 0; i < n_ops; ++i) {
@@ -312,17 +285,6 @@ static int unet_forward_impl(const pbn_unet_op* ops, int n_ops, const pbn_unet_b
         }
         if (events) PBN_HIP_CHECK(hipEventRecord(events[2 * i], (hipStream_t)stream));
         g_rows_hint = (hint && hint->armed && n_rows_dev) ? hint->rows[o.level_out] : 0;
-        g_rs_table = RsTableRef{nullptr, nullptr, 0};
-        if (o.map_kind == 1 && rs_tab[o.level_out] && rs_staged_pays(n_rows[o.level_out], o.cout_p / 16)) {
-            const int l = o.level_out;
-            if (!rs_tab_built[l]) {        // (inside the op's event bracket: the first layer of a level pays for the map's tables)
-                const int brc = pbn_rs_table_build(nbr, 27, n_rows_dev ? n_rows_dev + l : nullptr, n_rows[l], rs_tab[l],
-                                                   pbn_rs_table_bytes(n_rows[l], 27), stream);
-                if (brc != PBN_OK) return brc;
-                rs_tab_built[l] = true;
-            }
-            g_rs_table = RsTableRef{nbr, rs_tab[l], n_rows[l]};
-        }
         int rc = PBN_ERR_UNSUPPORTED;
         if (o.in2_buf >= 0) {           // a BasicBlock's 1x1 shortcut folded into this convolution's reduction
             if (o.in2_buf >= n_bufs) return PBN_ERR_ARG;

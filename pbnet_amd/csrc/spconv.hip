@@ -615,7 +615,6 @@ static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const i
     // with the other scenes' working sets for the same L2s and every op reads 1.1 MB more.  Off by default.
     static const int pf_env = getenv("PBN_CONV_PREFETCH") ? atoi(getenv("PBN_CONV_PREFETCH")) : 0;   // 0 off, 1 with ownership, 2 plain slices
     a.pf_w = nullptr; a.pf_steps = a.pf_ntt = a.pf_nt = a.pf_groups = 0;
-    a.rs_table = (nbr && g_rs_table.nbr == nbr && g_rs_table.n_out == n_out && n_in == n_out) ? g_rs_table.table : nullptr;
     if (pf_env && g_next_weights.w) {
         a.pf_w = g_next_weights.w; a.pf_steps = g_next_weights.steps; a.pf_ntt = g_next_weights.ntt;
         a.pf_nt = g_next_weights.nt; a.pf_groups = pf_env == 1 ? g_next_weights.groups : 0;
@@ -624,8 +623,21 @@ static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const i
     a.dbg = dbg_env;
     // coarse levels (and whatever PBN_CONV_FAMILY selects): the wave-autonomous family of spconv_wave.hip -- K split over
     // the waves of a workgroup instead of over workgroups: no fp32 partial slabs, no second launch
-    if (rows_per_wave >= 10000) return launch_rs(a, dtype, rows_per_wave - 10000, stream);   // explicit row-stationary configuration
+    if (rows_per_wave >= 10000) {             // explicit configuration of the big-tile families: 10000 + 1000 * form + ... (tests, tuning)
+        const int c = rows_per_wave - 10000;
+#ifdef PBN_EXPERIMENTS
+        if ((c % 100000) / 1000 == 3) return launch_pc(a, dtype, (c / 100000) * 16, stream);   // form 3: pair-compacted (experiments/spconv_pc.hip)
+#endif
+        return launch_rs(a, dtype, c, stream);
+    }
     if (rows_per_wave >= 100) return launch_wave(a, dtype, rows_per_wave, stream);   // explicit configuration (tests, tuning)
+#ifdef PBN_EXPERIMENTS
+    // pair-compacted fragments, fp32 output tile in LDS (experiments/spconv_pc.hip; PBN_CONV_PC=1 in the experiments library)
+    if (rows_per_wave == 0 && pc_family_wanted(a, dtype)) {
+        const int rc = launch_pc(a, dtype, 0, stream);
+        if (rc != PBN_ERR_UNSUPPORTED) return rc;
+    }
+#endif
     // wide levels (round 5): one tile per CU, weights streamed once per CU (spconv_rs.hip)
     if (rows_per_wave == 0 && rs_family_wanted(a, dtype)) {
         const int rc = launch_rs(a, dtype, 0, stream);
@@ -649,7 +661,6 @@ static int spconv_forward_impl(const void* in_feat, int ld_in, int n_in, const i
 
 namespace pbn {
 thread_local NextWeights g_next_weights = {nullptr, 0, 0, 0, 0};
-thread_local RsTableRef g_rs_table = {nullptr, nullptr, 0};
 thread_local int g_rows_hint = 0;
 }
 
@@ -662,20 +673,6 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, cons
     return spconv_forward_impl(in_feat, ld_in, n_in, nbr, n_offsets, row_perm, n_out_dev, n_out, w_packed, vecs_per_offset,
                                n_steps, cout_padded, scale, shift, residual, ld_res, relu, out_feat, ld_out, dtype,
                                rows_per_wave, workspace, workspace_bytes, stream_, nullptr, 0, 0, 0);
-}
-
-// pbn_spconv_forward with the map's row-stationary tables (pbn_rs_table_build; null = none)
-extern "C" int pbn_spconv_forward_tab(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,
-                                      const int32_t* n_out_dev, int n_out, const void* w_packed, int vecs_per_offset, int n_steps,
-                                      int cout_padded, const float* scale, const float* shift, const void* residual, int ld_res,
-                                      int relu, void* out_feat, int ld_out, int dtype, int rows_per_wave, void* workspace,
-                                      size_t workspace_bytes, const void* rs_table, pbn_stream_t stream_) {
-    g_rs_table = RsTableRef{nbr, rs_table, n_out};
-    const int rc = spconv_forward_impl(in_feat, ld_in, n_in, nbr, n_offsets, nullptr, n_out_dev, n_out, w_packed, vecs_per_offset,
-                                       n_steps, cout_padded, scale, shift, residual, ld_res, relu, out_feat, ld_out, dtype,
-                                       rows_per_wave, workspace, workspace_bytes, stream_, nullptr, 0, 0, 0);
-    g_rs_table = RsTableRef{nullptr, nullptr, 0};
-    return rc;
 }
 
 extern "C" int pbn_spconv_forward_dual(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,

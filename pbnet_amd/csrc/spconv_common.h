@@ -44,18 +44,12 @@ struct ConvArgs {
     // cache when the next launch starts.  pf_groups = channel-tile groups of the next launch (0 = no ownership: plain slices)
     const void* pf_w;
     int pf_steps, pf_ntt, pf_nt, pf_groups;
-    // round 5: per-map tables of the staged row-stationary kernel (pbn_rs_table_build), or null: the kernel builds them itself
-    const void* rs_table;
 };
 
 // what the executor knows about the launch an op will turn into (spconv_wave.hip: describe_launch)
 struct LaunchDesc { int wave_family, nt, groups, wmajor; };
 struct NextWeights { const void* w; int steps, ntt, nt, groups; };
 extern thread_local NextWeights g_next_weights;     // set by the executor around pbn_spconv_forward (spconv.hip)
-// round 5: the tables of ONE map (spconv_rs.hip), set by the executor (or pbn_spconv_forward_tab) around a convolution call and
-// cleared behind it; a launch whose map is `nbr` uses them
-struct RsTableRef { const int* nbr; const void* table; int n_out; };
-extern thread_local RsTableRef g_rs_table;
 // round 5: expected rows of the NEXT convolution call's output level (capacity-planned forwards: n_out is a capacity 1.25 x larger,
 // and choosing families / tile shapes by it picks slower kernels); 0 = none.  Set by the executor around a call, cleared behind it
 extern thread_local int g_rows_hint;
@@ -181,7 +175,14 @@ void describe_launch(const ConvArgs& a, int dtype, LaunchDesc* d);
 
 // spconv_rs.hip (round 5): row-stationary big-tile family for the wide levels.  cfg 0 = automatic tile height, 1..5 = fragments per wave
 bool rs_family_wanted(const ConvArgs& a, int dtype);
-bool rs_staged_pays(int n_out, int ntiles_total);      // a k = 3 cube map of this size is worth its tables (pbn_rs_table_build)
 int launch_rs(const ConvArgs& a, int dtype, int cfg, hipStream_t stream);
+
+
+#ifdef PBN_EXPERIMENTS
+// experiments/spconv_pc.hip (round 6, `make experiments` only): pair-compacted family for the wide levels (fp32 output tile in
+// LDS, fragments of 16 real rule pairs).  rows: 0 = automatic tile height, otherwise the tile height
+int launch_pc(const ConvArgs& a, int dtype, int rows, hipStream_t stream);
+bool pc_family_wanted(const ConvArgs& a, int dtype);
+#endif
 
 }  // namespace pbn

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pbnet_amd.MinkowskiEngine as ME
 from pbnet_amd import synth
-from pbnet_amd.MinkowskiEngine.conv import spconv_forward, spconv_forward_tab, RsTable
+from pbnet_amd.MinkowskiEngine.conv import spconv_forward
 dev = "cuda:0"
 REP = 20
 STREAMS = int(os.environ.get("PBN_PROBE_STREAMS", "1"))
@@ -66,13 +66,8 @@ def run(level, cin, cout, k=3):
     shift = torch.randn(cp, device=dev)
     res = torch.randn(n_out, cp, device=dev).to(DT)
     outs, line = {}, "L%d rows=%6d %3d->%3d K=%2d %s:" % (level, n_out, cin, cout, nbr.shape[1], str(DT).split(".")[-1])
-    tab = RsTable(nbr, n_out) if (any(c >= 20000 for c in CFGS) and nbr.shape[1] == 27) else None
     for cfg in CFGS:
         def call(o, cfg=cfg):
-            if cfg >= 20000:      # 2xxxx: the same configuration with the map's tables
-                if tab is None:
-                    raise RuntimeError("no table")
-                return spconv_forward_tab(x, tab, packed, scale=scale, shift=shift, residual=res, relu=True, out=o, rows_per_wave=cfg - 10000)
             return spconv_forward(x, nbr, n_out, packed, scale=scale, shift=shift, residual=res, relu=True, out=o, rows_per_wave=cfg)
         try:
             o = torch.zeros(n_out, cp, dtype=DT, device=dev)
