@@ -58,7 +58,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_SUMMARIES = ("r05_f_pmc_summary.json", "r05_e_pmc_summary.json", "r05_d_pmc_summary.json", "r05_c_pmc_summary.json", "r05_b_pmc_summary.json", "r05_a_pmc_summary.json", "r04_d_pmc_summary.json", "r04_c_pmc_summary.json", "r04_b_pmc_summary.json", "r04_a_pmc_summary.json", "r03_c_pmc_summary.json", "r03_b_pmc_summary.json", "r03_a_pmc_summary.json", "r02_b_pmc_summary.json", "r02_a_pmc_summary.json", "r01_pmc_summary.json")   # newest first
+PMC_SUMMARIES = ("r06_b_pmc_summary.json", "r06_a_pmc_summary.json", "r05_f_pmc_summary.json", "r05_e_pmc_summary.json", "r05_d_pmc_summary.json", "r05_c_pmc_summary.json", "r05_b_pmc_summary.json", "r05_a_pmc_summary.json", "r04_d_pmc_summary.json", "r04_c_pmc_summary.json", "r04_b_pmc_summary.json", "r04_a_pmc_summary.json", "r03_c_pmc_summary.json", "r03_b_pmc_summary.json", "r03_a_pmc_summary.json", "r02_b_pmc_summary.json", "r02_a_pmc_summary.json", "r01_pmc_summary.json")   # newest first
 
 
 WORKLOADS = {
@@ -156,6 +156,50 @@ def timed_leg(model, b, t, inflight, device, steps, warmup=None, blocks=3):
     return steps / e, e / steps * 1e3, alone, r.result()
 
 
+def served_legs(model, dtype, device, inflight, seconds=1.2):
+    """scenes/s of the serving front over a grid of (scenes per forward B, forwards in flight F); the best cell is `value`."""
+    from pbnet_amd import synth
+    from pbnet_amd.serving import SceneServer
+    scenes = []
+    for sd in range(2, 10):
+        bt, tc, inf = synth.make_val_batch(copies=1, **dict(WORKLOADS["c2"], seed=sd))
+        sc = {k: torch.from_numpy(bt[k]).to(device) for k in ("xyz_voxel", "feat_voxel", "xyz_original", "v2p_index")}
+        sc["feat_voxel"] = sc["feat_voxel"].to(dtype)
+        scenes.append((sc, {k: torch.from_numpy(v).to(device) for k, v in tc.items()}, inf["n_points"]))
+    torch.cuda.synchronize()
+    streams = inflight_streams(device, inflight)
+    grid, best = {}, None
+    for B, F in ((1, 4), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2)):
+        if F > len(streams):
+            continue
+        srv = SceneServer(model, max_batch=B, forwards_in_flight=F, streams=streams[:F])
+        try:
+            def burst(n):
+                futs = [srv.submit(scenes[i % 8][0], scenes[i % 8][1]) for i in range(n)]
+                return [f.result(timeout=600) for f in futs]
+            burst(2 * B * F)                                  # warm-up: pools grow to the merged sizes
+            n = 2 * B * F
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); burst(n); dt = time.perf_counter() - t0
+            n = max(2 * B * F, int(n * seconds / max(dt, 1e-3)) // (B * F) * (B * F))
+            f0 = srv.forwards
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); res = burst(n); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            cell = {"value": round(n / dt, 3), "scenes": n, "forwards": srv.forwards - f0,
+                    "proposals_per_scene": round(float(np.mean([int(r["proposals"][1].shape[0]) - 1 for r in res])), 1)}
+        finally:
+            srv.close()
+        grid["B%dxF%d" % (B, F)] = cell
+        if best is None or cell["value"] > best[1]["value"]:
+            best = ("B%dxF%d" % (B, F), cell)
+        torch.cuda.empty_cache()
+    return {"value": best[1]["value"], "unit": "scenes/s", "best": best[0], "grid": grid,
+            "scene_stream": "8 distinct configs[1] scenes (seeds 2..9, %d-%d points), submitted in bursts; every scene gets its own result back "
+                            "(proposals renumbered, point indices local)" % (min(s[2] for s in scenes), max(s[2] for s in scenes)),
+            "note": "pbnet_amd/serving.py: B = scenes merged per forward through the reference's batch axis (PBNet.py:167-176, "
+                    "dataset_preprocess.py:296), F = forwards in flight; B1xF4 is the headline's mode with distinct scenes and the split"}
+
+
 def build_workload(rank, copies, dtype, device, workload="c2", world=1):
     cfg, model = build_model(device)
     b, t, info, raw = build_scene(copies, dtype, device, workload, seed=(10 + rank) if world > 1 else None)
@@ -228,6 +272,7 @@ class ConvProbe(object):
         self.flops = 0
         self.launches = 0
         self.levels = {}         # tensor stride of the output level -> [launches, ms, bytes, flops]
+        self.families = {}       # kernel family (pbn_spconv_family) -> [launches, ms, bytes, flops]
         self.py_records = []
         self.lock = threading.Lock()
 
@@ -238,6 +283,13 @@ class ConvProbe(object):
             return rows[min(lin, lout)]           # every fine voxel has exactly one parent
         nbr = cm.kernel_map(1 << lout, 3 if kind == 1 else 5)   # cm: the pyramid the executor ran on
         return int((nbr >= 0).sum().item())
+
+    FAMILY_NAMES = {0: "workgroup-tile (k_spconv)", 1: "wave-autonomous (k_spconv_wave)", 2: "row-stationary (k_spconv_rs)"}
+
+    def _family(self, n_out, k, vpo, n_steps, cout_p, esz, has_map):
+        from pbnet_amd import _native as N
+        dt = {4: 0, 2: 1}[esz]            # PBN_F32 / PBN_BF16 (fp16 chooses as bf16)
+        return self.FAMILY_NAMES.get(int(N.lib().pbn_spconv_family(int(n_out), int(k), int(vpo), int(n_steps), int(cout_p), dt, int(bool(has_map)))), "?")
 
     def unet_sink(self, model, plan, rows, cm, esz, op_ms):
         with self.lock:
@@ -273,6 +325,9 @@ class ConvProbe(object):
             self.launches += 1
             lv = self.levels.setdefault(1 << op.level_out, [0, 0.0, 0, 0])
             lv[0] += 1; lv[1] += op_ms[i]; lv[2] += nbytes; lv[3] += flops
+            fam = self._family(v_out, k, op.vpo, op.n_steps, op.cout_p, esz, op.map_kind != 0)
+            fv = self.families.setdefault(fam, [0, 0.0, 0, 0])
+            fv[0] += 1; fv[1] += op_ms[i]; fv[2] += nbytes; fv[3] += flops
 
     def install(self):
         from pbnet_amd.MinkowskiEngine import conv as C
@@ -340,7 +395,7 @@ def gpu_active(args):
     if args.copies != 1 or args.dtype != "bf16" or args.workload != "c2":
         return None
     out = {}
-    for tag in ("r05_f", "r05_e", "r05_d", "r05_c", "r05_b", "r05_a"):
+    for tag in ("r06_b", "r06_a", "r05_f", "r05_e", "r05_d", "r05_c", "r05_b", "r05_a"):
         for key, name in (("in_flight", "%s_bench_concurrency.json" % tag), ("one_scene", "%s_inflight1_concurrency.json" % tag),
                           ("in_flight_planned_eager", "%s_planned_concurrency.json" % tag),
                           ("in_flight_graph", "%s_graph_concurrency.json" % tag)):
@@ -354,6 +409,20 @@ def gpu_active(args):
             except (OSError, KeyError, ValueError):
                 continue
     return out or None
+
+
+def sq_summary():
+    """(groups, source) of the newest committed SQ counter summary that carries MFMA busy cycles per launch (round 6 on), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_conv_summary.json")), reverse=True):
+        try:
+            with open(path) as f:
+                g = json.load(f)["groups"]
+            if any("mfma_busy_cycles_per_launch" in v for v in g.values()):
+                return g, "profiles/" + os.path.basename(path)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def cpu_baseline(cfg, model, raw, runs=3):
@@ -473,7 +542,8 @@ def init_process_group(world, rank, device):
         want = world * (world + 1) / 2
         if float(probe[0]) != want:
             raise RuntimeError("all-reduce returned %r, expected %r" % (float(probe[0]), want))
-        return dist, "ok (backend nccl = RCCL, world %d: init, all-reduce, barrier)" % world
+        check = rccl_selfcheck(dist, world, rank, device)
+        return dist, {"status": "ok (backend nccl = RCCL, world %d: init, all-reduce, barrier)" % world, "selfcheck": check}
     except Exception as e:  # noqa: BLE001
         if world > 1:
             raise
@@ -483,6 +553,39 @@ def init_process_group(world, rank, device):
         except Exception:  # noqa: BLE001
             pass
         return None, "FAILED at world 1: %s: %s" % (type(e).__name__, str(e)[:200])
+
+
+def rccl_selfcheck(dist, world, rank, device, mb=64):
+    """Round 6: what the first real N-GPU run must show in its own output -- that RCCL moved a gradient-bucket-sized buffer
+    between N ranks and every rank got the right sum.  Element i of rank r's 64 MB fp32 bucket is (r + 1) * (1 + i % 7); after the
+    all-reduce every element must be W (W + 1) / 2 * (1 + i % 7) (small integers: exact in fp32), checked on EVERY rank; the
+    per-rank verdicts and times are all-gathered so that rank 0's JSON line carries them, and every rank prints its own line
+    to stderr.  Bus bandwidth = 2 (W - 1) / W x bytes / time (the ring all-reduce's traffic per link)."""
+    n = mb * (1 << 20) // 4
+    device = torch.device(device)
+    sync = (lambda: torch.cuda.synchronize(device)) if device.type == "cuda" else (lambda: None)
+    pattern = (torch.arange(n, device=device, dtype=torch.int32) % 7 + 1).float()
+    times = []
+    ok = True
+    for _ in range(3):
+        buf = pattern * float(rank + 1)
+        sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.all_reduce(buf)
+        sync()
+        times.append(time.perf_counter() - t0)
+        ok = ok and bool(torch.equal(buf, pattern * float(world * (world + 1) // 2)))
+    mine = torch.tensor([float(rank), 1.0 if ok else 0.0, min(times) * 1e3], device=device)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    rows = [[float(v) for v in t.cpu().tolist()] for t in allr]
+    sys.stderr.write("rccl self-check rank %d/%d: %s, %d MB all-reduce %.3f ms\n" % (rank, world, "ok" if ok else "WRONG SUM", mb, min(times) * 1e3))
+    sys.stderr.flush()
+    t_max = max(r[2] for r in rows) / 1e3
+    return {"bucket_mb": mb, "ranks_seen": len({int(r[0]) for r in rows}), "all_ok": all(r[1] == 1.0 for r in rows),
+            "per_rank": [{"rank": int(r[0]), "ok": r[1] == 1.0, "ms": round(r[2], 3)} for r in rows],
+            "bus_gb_per_s": round(2.0 * (world - 1) / world * mb * (1 << 20) / max(t_max, 1e-9) / 1e9, 1) if world > 1 else None}
 
 
 def spawn_ranks(args):
@@ -557,6 +660,7 @@ def dry_run(args):
     shard_sizes = torch.zeros(world, dtype=torch.int64)
     shard_sizes[rank] = len(mine)
     dist.all_reduce(shard_sizes)
+    check = rccl_selfcheck(dist, world, rank, "cpu", mb=4)      # the same self-check the GPU run makes over RCCL, here over gloo
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
@@ -568,7 +672,7 @@ def dry_run(args):
                           "config": {"workload": "stand-in step on the host: launch plumbing only, NOT a measurement",
                                      "local_rank_of_rank0": local_rank, "scene_shard_sizes": shard_sizes.tolist(),
                                      "host_threads_per_rank": max(1, args.inflight),
-                                     "rccl": "not used (gloo)"},
+                                     "rccl": {"status": "not used (gloo)", "selfcheck": check}},
                           "roofline": None}), flush=True)
 
 
@@ -702,6 +806,25 @@ def main():
                 leg["by_level"].append({"tensor_stride": stride, "launches_per_step": c // n, "avg_launch_us": round(ms * 1e3 / c, 2),
                                         "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                                         "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2)})
+            # round 6: the same split per kernel FAMILY (which family pbn_spconv_forward's automatic choice gives each op), and
+            # against the SQ counters of the newest committed profile: MFMAs issued (busy cycles / 16) over the MFMAs the
+            # launches' rule pairs need (flops / 16 384 per 16x16x32 MFMA; true channel counts)
+            sq = sq_summary()
+            leg["by_family"] = []
+            for fam in sorted(probe.families):
+                c, ms, by, fl = probe.families[fam]
+                gbs = by / (ms * 1e-3) / 1e9
+                row = {"family": fam, "launches_per_step": c // n, "avg_launch_us": round(ms * 1e3 / c, 2), "us_per_step": round(ms * 1e3 / n, 1),
+                       "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
+                key = {"workgroup-tile (k_spconv)": ("tile_family_wide", "tile_family_coarse"), "wave-autonomous (k_spconv_wave)": ("wave_family",),
+                       "row-stationary (k_spconv_rs)": ("row_stationary", "row_stationary_gather")}.get(fam, ())
+                if sq is not None:
+                    gs = [sq[0][k_] for k_ in key if k_ in sq[0] and "mfma_busy_cycles_per_launch" in sq[0][k_]]
+                    if gs:
+                        busy = sum(g_["mfma_busy_cycles_per_launch"] * g_["launches"] for g_ in gs) / sum(g_["launches"] for g_ in gs)
+                        row["mfma_issued_over_useful"] = round((busy / 16.0) / max(fl / c / 16384.0, 1.0), 2)
+                        row["mfma_source"] = sq[1]
+                leg["by_family"].append(row)
             return leg
 
         # the launches are timed in the mode the timed region ran in: with several scenes in flight a launch shares the
@@ -818,6 +941,11 @@ def main():
                                     "voxels_per_forward": ib["n_voxels"],
                                     "proposals_per_forward": int(rb["proposals"][1].shape[0] - 1)}
                 del bb, tb, rb
+                # round 6: the serving front (pbnet_amd/serving.py) -- the scenes waiting on the GPU merged into one forward through
+                # the reference's batch axis, B scenes per forward x F forwards in flight, per-scene results split afterwards;
+                # a stream of DISTINCT configs[1] scenes (seeds 2..9: 150-180 k points each)
+                legs["served"] = served_legs(model, dtype, device, args.inflight)
+                phase("served_legs")
                 # configs[3]: the dense 1 cm scene (rulebook build + gather/scatter stress)
                 b4, t4, i4, _ = build_scene(1, dtype, device, "c4")
                 v, ms, alone, r4 = timed_leg(model, b4, t4, args.inflight, device, max(args.inflight, k // 4), warmup=args.inflight)

@@ -184,6 +184,10 @@ int pbn_spconv_forward_dual(const void* in_feat, int ld_in, int n_in, const int3
                             size_t workspace_bytes, const void* in2_feat, int ld_in2, int n_in2, int vecs_second,
                             pbn_stream_t stream);
 
+/* Which kernel family pbn_spconv_forward's automatic choice (rows_per_wave = 0) gives a launch of this shape: 0 workgroup-tile
+ * (csrc/spconv.hip), 1 wave-autonomous (spconv_wave.hip), 2 row-stationary (spconv_rs.hip).  No launch; for reports. */
+int pbn_spconv_family(int n_out, int n_offsets, int vecs_per_offset, int n_steps, int cout_padded, int dtype, int has_map);
+
 /* out[i, :] = in[idx[i], :] on 16-byte multiples (voxel -> point gathers, network/PBNet.py:130-134,250); a negative
  * index gives a zero row (padding slots of the compacted weight-gradient operands). */
 int pbn_gather_rows(const void* in, int ld_in_bytes, const int64_t* idx, int n, int row_bytes, void* out,

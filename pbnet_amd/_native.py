@@ -102,6 +102,7 @@ SIGNATURES = {
     "pbn_spconv_forward_dual": (c_int, [c_vp, c_int, c_int, c_i32p, c_int, c_i32p, c_int, c_vp, c_int, c_int, c_int, c_f32p, c_f32p,
                                         c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp, c_int, c_int, c_int, c_vp]),
     "pbn_unet_set_rows_hint": (None, [c_i32p]),
+    "pbn_spconv_family": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "pbn_spconv_wgrad_workspace_bytes": (c_size, [c_int, c_int, c_int]),
     "pbn_spconv_wgrad": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_i32p, c_i32p, c_int, c_int, c_int, c_int, c_int,
                                  c_f32p, c_vp, c_size, c_vp]),

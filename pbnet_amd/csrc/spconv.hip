@@ -26,6 +26,7 @@
 // parity configuration (1e-4 vs the oracle); bf16/f16 slabs use v_mfma_f32_16x16x32_{bf16,f16}.
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include "spconv_common.h"
 
 namespace pbn {
@@ -673,6 +674,19 @@ extern "C" int pbn_spconv_forward(const void* in_feat, int ld_in, int n_in, cons
     return spconv_forward_impl(in_feat, ld_in, n_in, nbr, n_offsets, row_perm, n_out_dev, n_out, w_packed, vecs_per_offset,
                                n_steps, cout_padded, scale, shift, residual, ld_res, relu, out_feat, ld_out, dtype,
                                rows_per_wave, workspace, workspace_bytes, stream_, nullptr, 0, 0, 0);
+}
+
+// Which kernel family the automatic choice of pbn_spconv_forward gives a launch of this shape (0 workgroup-tile k_spconv,
+// 1 wave-autonomous k_spconv_wave, 2 row-stationary k_spconv_rs): the same predicates, no launch.  For reports (bench.py's family split).
+extern "C" int pbn_spconv_family(int n_out, int n_offsets, int vecs_per_offset, int n_steps, int cout_padded, int dtype, int has_map) {
+    if (n_out < 0 || n_offsets < 1 || vecs_per_offset < 1 || n_steps < 1 || cout_padded < 16 || (cout_padded & 15)) return PBN_ERR_ARG;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nbr = has_map ? reinterpret_cast<const int*>(&a) : nullptr;       // (only tested against null)
+    a.K = n_offsets; a.vpo = vecs_per_offset; a.n_steps = n_steps; a.ntiles_total = cout_padded / 16; a.n_out = a.n_sel = n_out;
+    if (has_map && rs_family_wanted(a, dtype)) return 2;
+    if (wave_family_wanted(a, dtype)) return 1;
+    return 0;
 }
 
 extern "C" int pbn_spconv_forward_dual(const void* in_feat, int ld_in, int n_in, const int32_t* nbr, int n_offsets,

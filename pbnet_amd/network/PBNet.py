@@ -42,7 +42,7 @@ FRONT_CLUSTER_CAP = 1024
 # ... and only up to this many points: the front's buffers, fills and grids are sized by the number of POINTS where the host path sizes
 # them by the selected points.  (Measured after k_count stopped folding the lanes past the count onto its last point: +2.5-3.5 % in
 # flight at 162 k points, level at 485 k and at 1.1 M points.)
-FRONT_MAX_POINTS = int(os.environ.get("PBNET_DEVICE_FRONT_MAX_POINTS", "1000000"))
+FRONT_MAX_POINTS = int(os.environ.get("PBNET_DEVICE_FRONT_MAX_POINTS", "2000000"))      # (round 6: 2 M -- eight merged scenes, pbnet_amd/serving.py)
 
 
 def _mlp(cin, mid, cout, sigmoid=False):
@@ -113,13 +113,17 @@ class PBNet(nn.Module):
                 nn.init.constant_(m.bn.bias, 0)
 
     # =========================================================================================================
-    def forward(self, feat_voxel, xyz_voxel, xyz_original, v2p_v1, ins_label, epoch, task="train", teacher=None):
+    def forward(self, feat_voxel, xyz_voxel, xyz_original, v2p_v1, ins_label, epoch, task="train", teacher=None, n_batch=None):
         """teacher: optional dict(sem_score [N,sem_num], offset [N,3]) that REPLACES the two head outputs after they
-        have been computed -- a bench/test hook: randomly initialised heads cannot produce instances."""
+        have been computed -- a bench/test hook: randomly initialised heads cannot produce instances.
+        n_batch: batch elements of a "test" forward (the batch indices are 0 .. n_batch - 1).  The reference hard-codes 3, its
+        three test-time copies of one scene (PBNet.py:167-170; dataset_preprocess.py:324); a serving front that merges the
+        scenes waiting on a GPU into one forward through the same batch axis (pbnet_amd/serving.py) passes their number."""
         dev = torch.device("cuda", torch.cuda.current_device())
         if feat_voxel.shape[0] == 0 or xyz_original.shape[0] == 0:
             raise ValueError("PBNet.forward: empty scene (0 voxels / 0 points)")
         fused = not torch.is_grad_enabled()           # inference: the stage glue runs as fused launches (stage_ops)
+        nb = self.batch_size if task == "train" else (3 if n_batch is None else int(n_batch))            # PBNet.py:167-170
         stage1 = self.backbone_stage(feat_voxel.to(dev), xyz_voxel.to(dev), v2p_v1.to(dev), fused)
         if teacher is not None:
             stage1["sem_pred_score_p"] = teacher["sem_score"].to(dev, stage1["sem_pred_score_p"].dtype)
@@ -128,7 +132,6 @@ class PBNet(nn.Module):
                 stage1["sem_pred_score_sfp"] = torch.softmax(stage1["sem_pred_score_p"].float(), 1).to(stage1["point_feat_p"].dtype)
                 stage1["sem_pred_p"] = stage1["sem_pred_score_p"].max(1)[1]
         if fused:
-            nb = self.batch_size if task == "train" else 3                          # PBNet.py:167-170
             stage1["sem_pred_p"], stage1["sem_prob_p"], stage1["table"], stage1["block_hist"] = \
                 stage_ops.sem_argmax_table(stage1["sem_pred_score_p"], stage1["batch_head_p"], nb)
         elif TRAIN_FUSED_GLUE and stage1["sem_pred_score_p"].is_cuda and epoch > self.cluster_epoch:
@@ -137,7 +140,6 @@ class PBNet(nn.Module):
             # no_grad; what gradients flow through (features gathered at those rows, the softmax scores) stays torch.
             # The same integers either way (tests/test_train_gpu.py); ~70 small launches fewer per step, in the part of the
             # forward where the GPU waits for the host.
-            nb = self.batch_size if task == "train" else 3
             with torch.no_grad():
                 sc = stage1["sem_pred_score_p"].detach()
                 stage1["sem_pred_p"], _, stage1["table"], stage1["block_hist"] = stage_ops.sem_argmax_table(
@@ -146,7 +148,7 @@ class PBNet(nn.Module):
                "offset_pred_p": stage1["offset_pred_p"]}
         if epoch > self.cluster_epoch:
             ret.update(self.cluster_stage(stage1, xyz_original.to(dev), None if ins_label is None else ins_label.to(dev),
-                                          task))
+                                          task, nb))
         return ret
 
     # ---- PBNet.py:117-136 -------------------------------------------------------------------------------------
@@ -188,7 +190,7 @@ class PBNet(nn.Module):
         return out
 
     # ---- PBNet.py:144-279 -------------------------------------------------------------------------------------
-    def cluster_stage(self, s1, xyz_original, ins_label, task):
+    def cluster_stage(self, s1, xyz_original, ins_label, task, n_batch=None):
         dev = xyz_original.device
         xyz_original = xyz_original.float()
         fused = "table" in s1
@@ -197,8 +199,8 @@ class PBNet(nn.Module):
         point_feat_p, offset_pred_p = s1["point_feat_p"], s1["offset_pred_p"]
         train_glue = fused and torch.is_grad_enabled()       # fused index work, differentiable features (see forward())
         sem_sfp = s1["sem_prob_p"].view(-1, 1) if (fused and not train_glue) else s1["sem_pred_score_sfp"]
-        self.cluster_batch = self.batch_size if task == "train" else 3          # PBNet.py:167-170
-        nb = self.cluster_batch
+        nb = n_batch if n_batch is not None else (self.batch_size if task == "train" else 3)          # PBNet.py:167-170
+        self.cluster_batch = nb
         n_cls = int(self.sem_num)
 
         # inference: gate, selection, grouping and local-scene plan on the device, ONE read-back (see DEVICE_FRONT)
@@ -649,10 +651,10 @@ def model_fn(batch, model, epoch, cfg, task="train"):
     return loss, pred, visual_dict, meter_dict
 
 
-def model_fn_eval(batch, model, epoch, cfg, task="test", teacher=None):
+def model_fn_eval(batch, model, epoch, cfg, task="test", teacher=None, n_batch=None):
     """PBNet.py:446-460."""
     ret = model(batch["feat_voxel"], batch["xyz_voxel"], batch["xyz_original"], batch["v2p_index"], None, epoch, task,
-                teacher=teacher)
+                teacher=teacher, n_batch=n_batch)
     pred = {"sem": ret["sem_pred_p"]}
     if epoch > cfg.cluster_epoch:
         pred["proposals"] = ret["proposals"]

@@ -19,10 +19,8 @@ def group(name, grid):
         return "reduce"
     if "k_spconv_wave<" in name:
         return "wave_family"
-    if "k_spconv_rsh<" in name:
-        return "row_stationary_staged"
     if "k_spconv_rs<" in name:
-        return "row_stationary_gather"
+        return "row_stationary"
     if "k_spconv<" in name:
         return "tile_family_wide" if grid >= 400 * 256 else "tile_family_coarse"
     return None
@@ -49,6 +47,10 @@ for g, a in sorted(agg.items()):
                         "wait_any_frac": round(c.get("SQ_WAIT_ANY", 0) / wc, 4),
                         "wait_inst_frac": round(c.get("SQ_WAIT_INST_ANY", 0) / wc, 4),
                         "active_inst_frac": round(c.get("SQ_ACTIVE_INST_ANY", 0) / wc, 4),
-                        "mfma_busy_over_simd_cycles_at_2.4GHz": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(a["us"] * 2400.0 * 1024.0, 1.0), 4)}
+                        "mfma_busy_over_simd_cycles_at_2.4GHz": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(a["us"] * 2400.0 * 1024.0, 1.0), 4),
+                        # round 6: the counter itself, per launch -- 16 busy cycles per v_mfma_f32_16x16x32_{bf16,f16} (8 passes of 2
+                        # cycles... measured: 17 cycles back to back on one SIMD, MI355X_MICROARCH.md), so busy / 16 = MFMAs ISSUED;
+                        # bench.py divides by the MFMAs the launches' rule pairs need (roofline.by_family[].mfma_issued_over_useful)
+                        "mfma_busy_cycles_per_launch": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(len(a["launches"]), 1), 1)}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res["groups"], indent=1))

@@ -37,6 +37,7 @@ def test_bench_entry_two_ranks():
     assert line["scaling"] == "weak" and line["higher_is_better"] is True and line["unit"] == "scenes/s"
     assert abs(line["value"] - 2 * 4 / (line["ms_per_step"] * 4e-3)) / line["value"] < 1e-3     # whole-job aggregate over both ranks
     assert line["config"]["scene_shard_sizes"] == [8, 8]                                       # 16 scenes, round-robin
+    assert line["config"]["rccl"]["selfcheck"]["ranks_seen"] == 2 and line["config"]["rccl"]["selfcheck"]["all_ok"]
     assert line["roofline"] is None
 
 
@@ -69,4 +70,6 @@ def test_bench_spawns_its_own_ranks_eight_ranks_four_threads():
     line = json.loads(lines[0])
     assert line["dry_run"] is True and line["n_gpus"] == 8 and line["steps"] == 16
     assert line["config"]["scene_shard_sizes"] == [8] * 8 and line["config"]["host_threads_per_rank"] == 4
+    chk = line["config"]["rccl"]["selfcheck"]              # the rank-stamped bucket all-reduce every rank verifies (RCCL on the GPU run)
+    assert chk["ranks_seen"] == 8 and chk["all_ok"] and [r["rank"] for r in chk["per_rank"]] == list(range(8))
 
