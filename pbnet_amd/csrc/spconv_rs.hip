@@ -341,7 +341,7 @@ int cu_count() {
 
 // tile height: the level cut into (a multiple of) one tile per CU, rounded up to whole fragments
 struct RsShape { int tile_rows, n_tiles, nf; };
-RsShape rs_shape(int n_sel, int force_nf, int force_rows = 0, int n_out = -1) {
+RsShape rs_shape(int n_sel, int force_nf, int force_rows = 0, int n_out = -1, int nf_max = RS_NF_MAX) {
     // n_sel: the rows the tile height is chosen for; n_out (>= n_sel: a capacity) the rows the tiles must cover
     if (n_out < 0) n_out = n_sel;
     RsShape s;
@@ -364,7 +364,7 @@ RsShape rs_shape(int n_sel, int force_nf, int force_rows = 0, int n_out = -1) {
         for (int rounds = 1;; ++rounds) {
             const int per = cdiv(n_sel, cus * rounds);
             s.tile_rows = ((per + 15) / 16) * 16;
-            if (s.tile_rows <= RS_NW * 16 * RS_NF_MAX) break;
+            if (s.tile_rows <= RS_NW * 16 * nf_max) break;
         }
         s.nf = cdiv(s.tile_rows, RS_NW * 16);
     }
@@ -388,14 +388,19 @@ int launch_rs_one(const ConvArgs& a, const RsShape& s, hipStream_t stream) {
     return PBN_OK;
 }
 
+// fragments per wave an instantiation is built for: 5 (640-row tiles) where the accumulators fit, 3 at 128 output channels
+// (8 channel tiles x 4 registers per fragment) -- round 6: the 64- and 128-channel shapes, for the levels that reach 20 k rows when
+// several scenes share a forward (pbnet_amd/serving.py) or the scene is dense (configs[3])
+constexpr int rs_nf_max(int nt, int cg) { return nt >= 8 ? 3 : ((nt == 6 && cg == 4) ? 4 : 5); }    // (6 tiles x 4 steps at 5 fragments spills)
+
 template <typename T, int NT, int CG, int RING>
 int launch_rs_nf(const ConvArgs& a, const RsShape& s, hipStream_t stream) {
     switch (s.nf) {
         case 1: return launch_rs_one<T, 1, NT, CG, RING>(a, s, stream);
         case 2: return launch_rs_one<T, 2, NT, CG, RING>(a, s, stream);
         case 3: return launch_rs_one<T, 3, NT, CG, RING>(a, s, stream);
-        case 4: return launch_rs_one<T, 4, NT, CG, RING>(a, s, stream);
-        case 5: return launch_rs_one<T, 5, NT, CG, RING>(a, s, stream);
+        case 4: if constexpr (rs_nf_max(NT, CG) >= 4) return launch_rs_one<T, 4, NT, CG, RING>(a, s, stream); else return PBN_ERR_UNSUPPORTED;
+        case 5: if constexpr (rs_nf_max(NT, CG) >= 5) return launch_rs_one<T, 5, NT, CG, RING>(a, s, stream); else return PBN_ERR_UNSUPPORTED;
         default: return PBN_ERR_UNSUPPORTED;
     }
 }
@@ -407,6 +412,13 @@ int launch_rs_t(const ConvArgs& a, const RsShape& s, int cg, hipStream_t stream)
     if (nt == 6 && cg == 4) return launch_rs_nf<T, 6, 4, 2>(a, s, stream);
     if (nt == 2 && cg == 1) return launch_rs_nf<T, 2, 1, 2>(a, s, stream);
     if (nt == 2 && cg == 2) return launch_rs_nf<T, 2, 2, 2>(a, s, stream);
+    if constexpr (!std::is_same<T, float>::value) {        // (16-bit slabs only: the parity configuration never reaches these levels' row counts)
+        if (nt == 4 && cg == 1) return launch_rs_nf<T, 4, 1, 2>(a, s, stream);
+        if (nt == 4 && cg == 2) return launch_rs_nf<T, 4, 2, 2>(a, s, stream);
+        if (nt == 8 && cg == 2) return launch_rs_nf<T, 8, 2, 2>(a, s, stream);
+        if (nt == 8 && cg == 3) return launch_rs_nf<T, 8, 3, 2>(a, s, stream);
+        if (nt == 8 && cg == 4) return launch_rs_nf<T, 8, 4, 2>(a, s, stream);
+    }
     return PBN_ERR_UNSUPPORTED;
 }
 
@@ -431,6 +443,8 @@ bool rs_family_wanted(const ConvArgs& a, int dtype) {
     const int cg = rs_cg(a);
     if (!cg) return false;
     const int nt = a.ntiles_total;
+    static const int wide = getenv("PBN_RS_WIDE") ? atoi(getenv("PBN_RS_WIDE")) : 1;       // round 6: 64 / 128 output channels
+    if (wide && ((nt == 4 && cg <= 2) || (nt == 8 && cg >= 2))) return true;
     return (nt == 6 && (cg == 3 || cg == 4)) || (nt == 2 && cg == 1 && a.n_sel >= min_rows2);
 }
 
@@ -444,11 +458,10 @@ int launch_rs(const ConvArgs& a, int dtype, int cfg, hipStream_t stream) {
     if (!cg || !a.nbr || a.row_perm || a.K > 32 || cfg < 0 || cfg > RS_NF_MAX) return PBN_ERR_UNSUPPORTED;   // (identity maps stay on the other families)
     if (a.in2 && ((a.vpo2 & 3) || a.n_main % cg || a.n_steps % cg)) return PBN_ERR_UNSUPPORTED;
     if (!a.in2 && a.n_steps % cg) return PBN_ERR_UNSUPPORTED;
-    if (cfg == 0 && force_rows == 0 && a.ntiles_total == 6 && cg == 4 && rs_shape(a.n_sel, 0, 0, a.n_out).nf == 5)
-        cfg = 3;       // 128 input channels at 5 fragments per wave spill: 3 fragments, two rounds of smaller tiles
+    if (cfg > rs_nf_max(a.ntiles_total, cg)) return PBN_ERR_UNSUPPORTED;
     ConvArgs b = a;
     b.cg = cg;
-    const RsShape s = rs_shape(a.n_sel, cfg, force_rows, a.n_out);
+    const RsShape s = rs_shape(a.n_sel, cfg, force_rows, a.n_out, rs_nf_max(a.ntiles_total, cg));
     switch (dtype) {
         case PBN_BF16: return launch_rs_t<__hip_bfloat16>(b, s, cg, stream);
         case PBN_F16: return launch_rs_t<__half>(b, s, cg, stream);

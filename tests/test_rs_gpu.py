@@ -65,7 +65,7 @@ def _setup(cin, cout, k, dtype, coords):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL), (torch.bfloat16, 6e-2), (torch.float16, 1e-2)])
-@pytest.mark.parametrize("cin,cout", [(96, 96), (128, 96), (32, 32)])
+@pytest.mark.parametrize("cin,cout", [(96, 96), (128, 96), (32, 32), (64, 64), (128, 128), (192, 128), (32, 64)])
 def test_row_stationary_forms_against_the_oracle(dtype, tol, cin, cout):
     """Every fragment count, tile heights from one fragment per wave to the largest tile (and heights that leave waves with unequal
     fragment counts and a ragged last tile), with the full fused epilogue; run-to-run bit-identical; against the workgroup-tile
@@ -90,7 +90,8 @@ def test_row_stationary_forms_against_the_oracle(dtype, tol, cin, cout):
         _close(o1.float().cpu(), ref.float().cpu(), "row-stationary vs k_spconv cfg %d" % cfg, 1e-5 if dtype == torch.float32 else lim)
         _close(o1[:, :cout].float().cpu(), want, "rs nf %d rows %d %d->%d %s" % (nf, rows, cin, cout, dtype), lim)
         ran += 1
-    assert ran >= 6
+    # (the 64- and 128-channel shapes of round 6 are built for 16-bit slabs only, at up to 3 fragments per wave for 128 channels)
+    assert ran >= (0 if (dtype == torch.float32 and cout in (64, 128)) else (4 if cout == 128 else 6))
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL), (torch.bfloat16, 6e-2)])
