@@ -364,7 +364,10 @@ enum {
 };
 enum {
     PBN_OVF_POINTS = 1, PBN_OVF_CLUSTERS = 2, PBN_OVF_ENTRIES = 4, PBN_OVF_ROWS = 8, PBN_OVF_SEGMENT = 16,
-    PBN_OVF_BATCH = 32, PBN_OVF_LEVEL = 64
+    PBN_OVF_BATCH = 32, PBN_OVF_LEVEL = 64,
+    PBN_OVF_CDIST = 128     /* pbn_local_plan: a (class, batch) segment with more than 25 clusters needed its neighbours ranked --
+                             * torch.cdist (PBNet.py:201) switches to its matrix-multiply distance there, whose rounding can rank near-ties
+                             * differently from the direct d^2 of this plan: the caller takes the reference's own call (host plan) */
 };
 int pbn_class_gate(const int32_t* table, const float* thr05, int n_classes, int nb, int m_cap, int n_points,
                    int32_t* class_base, int32_t* seg_len, int32_t* counts, pbn_stream_t stream);

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(64) void k_class_gate(const int* __restrict__ table
 // scene c: entry 0 = cluster c with weight 1; if size(c) > count_mean * 0.2 and the segment has other clusters, the
 // para_k = min(C_b - 1, K_max) nearest clusters of the SAME (class, batch) segment follow with weights
 // 0.5 * (para_k + 1 - i) / (para_k + 1)  (PBNet.py:196-221).  Nearest = ascending (d^2, cluster id), d^2 = (dx^2+dy^2)+dz^2 in
-// unfused fp32 -- the reference sorts torch.cdist distances, the same order up to ties of the rounded distances.
+// unfused fp32 -- the reference sorts torch.cdist distances, the same order up to ties of the rounded distances; segments of more
+// than 25 clusters raise PBN_OVF_CDIST (torch.cdist's matrix-multiply path: the caller falls back to the reference's own call).
 __global__ __launch_bounds__(64) void k_plan_scenes(const int* __restrict__ cluster_num, int n_seg, int nb,
                                                    const int* __restrict__ member_start, const float* __restrict__ centers,
                                                    const float* __restrict__ thr02, const int* __restrict__ kmax,
@@ -102,6 +103,10 @@ __global__ __launch_bounds__(64) void k_plan_scenes(const int* __restrict__ clus
         if (lane == 0) { scene_n_ent[gid] = 1; atomicOr(&counts[PBN_CNT_OVERFLOW], PBN_OVF_SEGMENT); }
         return;
     }
+    // more than 25 clusters in the segment: torch.cdist (the reference's call, PBNet.py:201) computes these distances through a
+    // matrix multiply, not as direct differences -- nearly equidistant clusters can rank differently.  The plan below is still
+    // written (same order unless two rounded distances tie), the flag lets the caller take the reference's own call instead
+    if (cb > 25 && lane == 0) atomicOr(&counts[PBN_CNT_OVERFLOW], PBN_OVF_CDIST);
     const float cx = centers[3 * gid + 0], cy = centers[3 * gid + 1], cz = centers[3 * gid + 2];
     for (int j = lane; j < cb; j += 64) {
         const int o = g0 + j;

@@ -32,7 +32,7 @@ from .MinkowskiEngine.conv import _DT, SPLITK_WORKSPACE_BYTES
 
 CNT = SimpleNamespace(POINTS=0, CLUSTERS=1, ENTRIES=2, ROWS=3, SCENES=4, PROPOSAL_ROWS=5, PROPOSALS=6, OVERFLOW=7, WORDS=16)
 OVF_NAMES = {1: "selected points", 2: "clusters", 4: "local-scene entries", 8: "local-scene rows",
-             16: "clusters of one (class, batch) segment", 32: "batch index outside [0, cluster_batch)", 64: "rows of a level"}
+             16: "clusters of one (class, batch) segment", 32: "batch index outside [0, cluster_batch)", 64: "rows of a level", 128: "a segment of more than 25 clusters (torch.cdist ranks through its matrix-multiply path: host plan)"}
 MASK_THD = 0.45
 LOCAL_VOXEL = 0.02
 _DEBUG = os.environ.get("PBN_PLANNED_DEBUG", "0") == "1"

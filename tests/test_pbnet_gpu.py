@@ -254,3 +254,37 @@ def test_device_front_equals_host_front_and_falls_back(setup, monkeypatch):
         for h, d, f in zip(host, devf, fell):
             assert h.dtype == d.dtype and torch.equal(h, d)
             assert torch.equal(h, f)
+
+
+def test_more_than_25_clusters_in_a_segment_take_the_reference_plan(setup, monkeypatch):
+    """torch.cdist (PBNet.py:201) computes distances through a matrix multiply once a segment has more than 25
+    clusters, and nearly equidistant clusters can then rank differently from the device plan's direct d^2.  Such a forward
+    raises PBN_OVF_CDIST and is served by the host plan -- the reference's own cdist / topk call: a scene with ~35 instances of ONE
+    class returns exactly what the host front returns, and the device plan was in fact left (the flag is read back)."""
+    import pbnet_amd.network.PBNet as PB
+    cfg, model, _, _, _ = setup
+    dev = "cuda:0"
+    b, t, _ = synth.make_val_batch(seed=9, copies=1, room=(3.2, 2.6, 1.4), n_boxes=36, pitch=0.03, classes=(5,))
+    b = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+    t = {k: torch.from_numpy(v).to(dev) for k, v in t.items()}
+
+    def run():
+        with torch.no_grad():
+            r = model(b["feat_voxel"], b["xyz_voxel"], b["xyz_original"], b["v2p_index"], None, 1, "test", teacher=t, n_batch=1)
+        return [r["proposals"][0].cpu(), r["proposals"][1].cpu(), r["clt_scores"].cpu()]
+    seen = []
+    orig = PB.PBNet._device_front
+
+    def spy(self, *a, **k):
+        out = orig(self, *a, **k)
+        seen.append(out is None)
+        return out
+    monkeypatch.setattr(PB.PBNet, "_device_front", spy)
+    monkeypatch.setattr(PB, "DEVICE_FRONT", True)
+    got = run()
+    monkeypatch.setattr(PB, "DEVICE_FRONT", False)
+    want = run()
+    assert seen and seen[0], "the device front did not report the > 25-cluster segment"
+    assert want[1].shape[0] - 1 >= 26, "the scene yields more than 25 proposals of one class (%d)" % (want[1].shape[0] - 1)
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
