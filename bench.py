@@ -169,7 +169,7 @@ def served_legs(model, dtype, device, inflight, seconds=1.2):
     torch.cuda.synchronize()
     streams = inflight_streams(device, inflight)
     grid, best = {}, None
-    for B, F in ((1, 4), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2)):
+    for B, F in ((1, 4), (2, 2), (2, 4), (3, 3), (3, 4), (4, 1), (4, 2), (4, 3), (4, 4), (6, 2), (6, 3), (8, 1), (8, 2)):
         if F > len(streams):
             continue
         srv = SceneServer(model, max_batch=B, forwards_in_flight=F, streams=streams[:F])
